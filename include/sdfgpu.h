@@ -1,0 +1,215 @@
+/*
+ * sdfgpu.h -- C ABI of the MI355X nearest-primitive / sphere-trace path.
+ *
+ * The reference crate has no FFI; the seam its author designed as the GPU
+ * hand-off is
+ *     faux_shader::nearest_neighbor(sdf_tree: &SdfTreeBuffer, point: Vec4) -> f32
+ *     (sdf/src/faux_shader.rs:96)
+ * over the #[repr(C)] records of sdf/src/component.rs:11-78 (see sdf_blocks.h).
+ * Every entry point below cites the reference item it replaces.  A Rust
+ * `extern "C"` block binding exactly these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - one context per GPU, one process per GPU (multi-GPU = one process per
+ *    device, partitioned by tile / query range; see sdfgpu_render_tiles_dev);
+ *  - every function returns 0 on success or a negative sdfgpu_status; the
+ *    reference's panic!/assert! sites become error codes, nothing unwinds;
+ *  - host-pointer entry points copy in, run, copy out and synchronise;
+ *    `_dev` entry points take device pointers and a hipStream_t (as void*) and
+ *    are asynchronous with respect to the host;
+ *  - the caller owns every buffer it passes; the context owns the uploaded
+ *    tree and its own scratch.  A context is not thread-safe.
+ */
+#ifndef SDFGPU_H
+#define SDFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "sdf_blocks.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdfgpu_ctx sdfgpu_ctx;
+
+typedef enum sdfgpu_status {
+    SDFGPU_OK = 0,
+    SDFGPU_ERR_INVALID_ARG = -1,
+    SDFGPU_ERR_HIP = -2,             /* a HIP runtime call failed (message has the detail) */
+    SDFGPU_ERR_NO_TREE = -3,         /* query before sdfgpu_upload_tree */
+    SDFGPU_ERR_LAYOUT = -4,          /* record stride / layout not the SSE2 one */
+    SDFGPU_ERR_BAD_TREE = -5,        /* len/level/shape invariants of make_buffer violated */
+    SDFGPU_ERR_UNSUPPORTED_OP = -6,  /* faux_shader.rs:65,80,92 panic! sites */
+    SDFGPU_ERR_TOO_DEEP = -7,        /* level >= 255 (faux_shader.rs:100 stack of 256) */
+    SDFGPU_ERR_NON_FINITE = -8,      /* NaN/Inf in a matrix the path evaluates (SURVEY C-10) */
+    SDFGPU_ERR_POINT_W = -9,         /* a host query point has w != 1 */
+    SDFGPU_ERR_TOO_LARGE = -10       /* k > SDFGPU_MAX_K, image too large, ... */
+} sdfgpu_status;
+
+/* Record layouts a producer may have (SURVEY 8b "layout caveat"). */
+typedef enum sdfgpu_layout {
+    SDFGPU_LAYOUT_GLAM_SSE2 = 0      /* 624-byte down blocks, 224-byte up blocks */
+} sdfgpu_layout;
+
+/* How the kernels bound subtrees.  All modes return the same (distance, index)
+ * on geometrically consistent buffers; see DESIGN.md "bounds". */
+typedef enum sdfgpu_bounds {
+    SDFGPU_BOUNDS_AUTO = 0,   /* AABB if the tree qualifies, else NONE */
+    SDFGPU_BOUNDS_AABB = 1,   /* world AABBs recomputed bottom-up from the leaves at upload */
+    SDFGPU_BOUNDS_OBB = 2,    /* the buffer's own boxes: MINDIST of faux_shader.rs:54-58, with a margin */
+    SDFGPU_BOUNDS_NONE = 3    /* no pruning: every primitive is evaluated (always valid) */
+} sdfgpu_bounds;
+
+#define SDFGPU_MAX_K 16u
+
+typedef struct sdfgpu_tree_info {
+    uint32_t n_nodes;        /* = buffer_len */
+    uint32_t n_prims;
+    uint32_t n_inner;
+    uint32_t max_level;      /* deepest `level` (root = 1) */
+    uint32_t bounds;         /* sdfgpu_bounds actually in use */
+    uint32_t identity_inner; /* 1 if every internal trans_inverse is exactly I */
+    uint32_t rigid_leaves;   /* 1 if every leaf trans_inverse is a rigid motion (tol 1e-4) */
+    uint32_t reserved;
+    uint64_t device_bytes;   /* compact tree bytes resident in HBM */
+    float scene_lo[3];       /* root AABB (AABB mode) */
+    float scene_hi[3];
+} sdfgpu_tree_info;
+
+/* Pinhole camera as plain data.  Ray through pixel (x, y):
+ *   pw  = (origin + du * x) + dv * y        (per component, each op rounded)
+ *   dir = (pw - eye) / |pw - eye|
+ * mirrors the only ray the reference defines (src/main__.rs:96-97:
+ * normalize(world_position - camera_position)). */
+typedef struct sdfgpu_camera {
+    float eye[3];
+    float origin[3];  /* world position of the centre of pixel (0,0) */
+    float du[3];      /* world step per pixel along +x */
+    float dv[3];      /* world step per pixel along +y */
+} sdfgpu_camera;
+
+/* Sphere-trace parameters.  The reference has no march loop; the
+ * loop is defined in DESIGN.md and restated by oracle/oracle.cpp::oracle_render.
+ * normal_h is the `h` of calcSphereNormal (src/main__.rs:152, 0.0001 there). */
+typedef struct sdfgpu_march_params {
+    uint32_t max_steps;
+    float eps_hit;
+    float t_min;
+    float t_max;
+    float normal_h;
+    uint32_t flags;   /* reserved, 0 */
+} sdfgpu_march_params;
+
+/* Per-launch work counters (instrumented variant of the same kernels). */
+typedef struct sdfgpu_stats {
+    uint64_t queries;        /* NN queries issued (one per lane per march step / per point) */
+    uint64_t inner_visits;   /* internal-node visits, summed over lanes */
+    uint64_t sphere_evals;   /* primitive evaluations, summed over lanes */
+    uint64_t box_evals;
+    uint64_t wave_inner;     /* the same, counted once per wavefront */
+    uint64_t wave_leaf;
+    uint64_t steps;          /* march steps summed over rays */
+    uint64_t rays;
+} sdfgpu_stats;
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* No reference counterpart (the crate is a CPU library). */
+int sdfgpu_create(int device_id, sdfgpu_ctx** out);
+void sdfgpu_destroy(sdfgpu_ctx* ctx);
+const char* sdfgpu_last_error(const sdfgpu_ctx* ctx);
+const char* sdfgpu_status_string(int status);
+int sdfgpu_sync(sdfgpu_ctx* ctx);
+
+/* ---- tree upload ------------------------------------------------------- */
+/* Takes what ExpandedSdfNode::make_buffer returns (sdf/src/node.rs:75-138):
+ * `dt` = downtree_buffer.as_ptr(), `ut` = uptree_buffer.as_ptr(),
+ * `buffer_len` = SdfTreeBuffer::buffer_len (component.rs:80-86).  Validates
+ * everything the kernels rely on, compacts the 624+224-byte records into the
+ * resident node arrays and copies them to HBM.  Replaces the `&SdfTreeBuffer`
+ * borrow of faux_shader.rs:96. */
+int sdfgpu_upload_tree(sdfgpu_ctx* ctx, const SdfOperationBlock* dt,
+                       const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
+                       uint32_t layout, uint32_t bounds);
+int sdfgpu_tree_info_get(const sdfgpu_ctx* ctx, sdfgpu_tree_info* out);
+/* The host half of sdfgpu_upload_tree alone (validation + compaction, no GPU
+ * touched): same status codes, message copied into errbuf.  For producers
+ * that want to check a buffer before shipping it. */
+int sdfgpu_compact_host(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
+                        uint32_t buffer_len, uint32_t layout, uint32_t bounds,
+                        sdfgpu_tree_info* info, char* errbuf, size_t errlen);
+
+/* ---- nearest primitive ------------------------------------------------- */
+/* faux_shader::nearest_neighbor (faux_shader.rs:96-208) for n points at once.
+ * pts_xyzw: n x 4 floats, w must be 1 (the crate only ever passes
+ * point.extend(1.0), node.rs:335,359).  out_dist[i] is the value the reference
+ * returns; out_prim[i] is the pre-order ordinal of the primitive attaining it
+ * (ties -> the later one, faux_shader.rs:27-29), SDF_NO_PRIM for an empty tree.
+ * out_prim may be NULL. */
+int sdfgpu_nearest(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n,
+                   float* out_dist, uint32_t* out_prim);
+/* Device-pointer form; the w component is not read (taken as 1). */
+int sdfgpu_nearest_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
+                       float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
+
+/* k nearest primitives (extension of the k = 1 reference, README.md:7):
+ * out_*[i*k + j], ascending by (distance, then larger index first), padded
+ * with (+inf, SDF_NO_PRIM). */
+int sdfgpu_knn(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n, uint32_t k,
+               float* out_dist, uint32_t* out_prim);
+int sdfgpu_knn_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n, uint32_t k,
+                   float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
+
+/* ---- sphere trace + normals -------------------------------------------- */
+/* Full frame, host pointers (each may be NULL except hit):
+ *   hit[w*h] u8, depth[w*h] f32 (+inf on miss), normal_xyz[3*w*h] f32
+ *   (0 on miss), prim[w*h] u32 (SDF_NO_PRIM on miss).
+ * Normals: tetrahedron finite difference against the hit primitive only,
+ * as calcSphereNormal does (src/main__.rs:151-161). */
+int sdfgpu_render(sdfgpu_ctx* ctx, const sdfgpu_camera* cam, uint32_t width,
+                  uint32_t height, const sdfgpu_march_params* mp, uint8_t* hit,
+                  float* depth, float* normal_xyz, uint32_t* prim);
+
+/* Tile-range form for the framebuffer partitioner.  The frame is cut into
+ * 8x8-pixel tiles numbered row-major; this call renders tiles
+ * tile_first, tile_first + tile_stride, ... (tile_count of them) and writes
+ * them compactly, tile after tile, 64 pixels each in row-major order inside
+ * the tile (pixels beyond the image edge are written as misses):
+ *   d_hit[tile_count*64], d_depth[...], d_normal_xyz[3*...], d_prim[...].
+ * Rank r of N passes tile_first = r, tile_stride = N. */
+int sdfgpu_render_tiles_dev(sdfgpu_ctx* ctx, const sdfgpu_camera* cam,
+                            uint32_t width, uint32_t height,
+                            const sdfgpu_march_params* mp, uint32_t tile_first,
+                            uint32_t tile_stride, uint32_t tile_count,
+                            uint8_t* d_hit, float* d_depth, float* d_normal_xyz,
+                            uint32_t* d_prim, void* hip_stream);
+
+/* Scatter tile-compact buffers (as written by sdfgpu_render_tiles_dev for the
+ * same tile_first/stride/count) into a row-major w x h frame on the device. */
+int sdfgpu_untile_dev(sdfgpu_ctx* ctx, uint32_t width, uint32_t height,
+                      uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
+                      const uint8_t* d_hit_t, const float* d_depth_t,
+                      const float* d_normal_t, const uint32_t* d_prim_t,
+                      uint8_t* d_hit, float* d_depth, float* d_normal_xyz,
+                      uint32_t* d_prim, void* hip_stream);
+
+/* ---- instrumentation ---------------------------------------------------- */
+/* Run the counting variant of the same kernels (slower) and return the work
+ * counters bench.py turns into algorithmic flops. */
+int sdfgpu_render_stats(sdfgpu_ctx* ctx, const sdfgpu_camera* cam, uint32_t width,
+                        uint32_t height, const sdfgpu_march_params* mp,
+                        sdfgpu_stats* out);
+int sdfgpu_nearest_stats_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
+                             sdfgpu_stats* out);
+
+/* Host helper: fill a sdfgpu_camera for a pinhole at `eye` looking at
+ * `target` (geometry of src/main__.rs:261-264), vertical field of view
+ * fov_y radians.  Pure host arithmetic in double, rounded once to float. */
+void sdfgpu_camera_look_at(const float eye[3], const float target[3],
+                           const float up[3], float fov_y, uint32_t width,
+                           uint32_t height, sdfgpu_camera* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFGPU_H */

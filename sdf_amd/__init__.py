@@ -1,0 +1,16 @@
+"""sdf_amd -- MI355X-native nearest-primitive / sphere-trace path of the sdf crate.
+
+Host side mirrors the crate's scene API (scene.py over sdf_amd/csrc/host);
+the queries run as hand-written gfx950 kernels behind the C ABI of
+include/sdfgpu.h (gpu.py).  Importing the package loads libsdfgpu.so and fails
+loudly if it has not been built.
+"""
+from . import _ffi
+from ._ffi import (BOUNDS_AABB, BOUNDS_AUTO, BOUNDS_NONE, BOUNDS_OBB, NO_PRIM,
+                   Camera, MarchParams, load_library)
+from .gpu import SdfGpu, SdfGpuError, camera_look_at, compact_host, march_params
+from .scene import (ExpandedSdfNode, Quat, SdfBox, SdfBuilder, SdfError, SdfNode,
+                    SdfSphere, SdfTreeBuffer, SdfUnion, Transform, default_extent,
+                    random_scene, random_scene_buffer)
+
+load_library()

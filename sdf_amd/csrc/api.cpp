@@ -1,0 +1,351 @@
+// api.cpp -- the C ABI of include/sdfgpu.h over the kernels.
+//
+// No CPU fallback exists anywhere in this file: every query entry point ends
+// in a kernel launch or returns an error code.  oracle/ is never referenced.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfgpu.h"
+#include "gpu_tree.hpp"
+#include "kernels.hpp"
+
+using namespace sdfgpu;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct sdfgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceTree tree;
+    bool has_tree = false;
+    sdfgpu_tree_info info{};
+    std::string err;
+    // grow-only scratch for the host-pointer entry points
+    DevBuf in, out_a, out_b, out_c, out_d, stats;
+};
+
+namespace {
+
+int set_err(sdfgpu_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+int hip_fail(sdfgpu_ctx* c, hipError_t e, const char* what) {
+    return set_err(c, SDFGPU_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
+    } while (0)
+
+int reserve(sdfgpu_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return SDFGPU_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SDFGPU_OK;
+}
+
+void free_tree(sdfgpu_ctx* c) {
+    if (c->tree.leaf) (void)hipFree(c->tree.leaf);
+    if (c->tree.inner) (void)hipFree(c->tree.inner);
+    if (c->tree.inner_obb) (void)hipFree(c->tree.inner_obb);
+    c->tree = DeviceTree();
+    c->has_tree = false;
+}
+
+int check_ready(sdfgpu_ctx* c) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    if (!c->has_tree) return set_err(c, SDFGPU_ERR_NO_TREE, "no tree uploaded (call sdfgpu_upload_tree first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return SDFGPU_OK;
+}
+
+int check_march(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h, const sdfgpu_march_params* mp) {
+    if (!cam || !mp) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null camera / march params");
+    if (w == 0 || h == 0) return set_err(c, SDFGPU_ERR_INVALID_ARG, "empty image");
+    if ((uint64_t)w * h > (1ull << 30)) return set_err(c, SDFGPU_ERR_TOO_LARGE, "image larger than 2^30 pixels");
+    return SDFGPU_OK;
+}
+
+template <class T>
+int upload_vec(sdfgpu_ctx* c, const std::vector<T>& v, T** dst) {
+    *dst = nullptr;
+    if (v.empty()) return SDFGPU_OK;
+    HIP_TRY(c, hipMalloc((void**)dst, v.size() * sizeof(T)));
+    HIP_TRY(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SDFGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sdfgpu_status_string(int s) {
+    switch (s) {
+        case SDFGPU_OK: return "ok";
+        case SDFGPU_ERR_INVALID_ARG: return "invalid argument";
+        case SDFGPU_ERR_HIP: return "HIP runtime error";
+        case SDFGPU_ERR_NO_TREE: return "no tree uploaded";
+        case SDFGPU_ERR_LAYOUT: return "unsupported record layout";
+        case SDFGPU_ERR_BAD_TREE: return "malformed tree buffer";
+        case SDFGPU_ERR_UNSUPPORTED_OP: return "unsupported op code";
+        case SDFGPU_ERR_TOO_DEEP: return "tree too deep";
+        case SDFGPU_ERR_NON_FINITE: return "non-finite value in tree";
+        case SDFGPU_ERR_POINT_W: return "query point with w != 1";
+        case SDFGPU_ERR_TOO_LARGE: return "size limit exceeded";
+    }
+    return "unknown status";
+}
+
+int sdfgpu_create(int device_id, sdfgpu_ctx** out) {
+    if (!out) return SDFGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SDFGPU_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return SDFGPU_ERR_HIP;
+    sdfgpu_ctx* c = new sdfgpu_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SDFGPU_ERR_HIP;
+    }
+    *out = c;
+    return SDFGPU_OK;
+}
+
+void sdfgpu_destroy(sdfgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_tree(c);
+    for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats})
+        if (b->p) (void)hipFree(b->p);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* sdfgpu_last_error(const sdfgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sdfgpu_sync(sdfgpu_ctx* c) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
+// Host-only half of upload: validation + compaction, no GPU needed.
+int sdfgpu_compact_host(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
+                        uint32_t layout, uint32_t bounds, sdfgpu_tree_info* info, char* errbuf, size_t errlen) {
+    CompactTree t;
+    std::string err;
+    int rc = compact_tree(dt, ut, buffer_len, layout, bounds, &t, &err);
+    if (info) *info = t.info;
+    if (errbuf && errlen) {
+        std::snprintf(errbuf, errlen, "%s", err.c_str());
+    }
+    return rc;
+}
+
+int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
+                       uint32_t buffer_len, uint32_t layout, uint32_t bounds) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    CompactTree t;
+    std::string err;
+    int rc = compact_tree(dt, ut, buffer_len, layout, bounds, &t, &err);
+    if (rc != SDFGPU_OK) return set_err(c, rc, err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_tree(c);
+    if ((rc = upload_vec(c, t.leaves, &c->tree.leaf)) != SDFGPU_OK) return rc;
+    if ((rc = upload_vec(c, t.inner, &c->tree.inner)) != SDFGPU_OK) return rc;
+    if ((rc = upload_vec(c, t.inner_obb, &c->tree.inner_obb)) != SDFGPU_OK) return rc;
+    c->tree.root_ref = t.root_ref;
+    c->tree.stack_depth = t.stack_depth;
+    c->tree.bounds = t.info.bounds;
+    c->tree.margin_T = t.margin_T;
+    c->info = t.info;
+    c->has_tree = true;
+    c->err.clear();
+    return SDFGPU_OK;
+}
+
+int sdfgpu_tree_info_get(const sdfgpu_ctx* c, sdfgpu_tree_info* out) {
+    if (!c || !out) return SDFGPU_ERR_INVALID_ARG;
+    if (!c->has_tree) return SDFGPU_ERR_NO_TREE;
+    *out = c->info;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_nearest_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, float* d_dist, uint32_t* d_prim, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (n == 0) return SDFGPU_OK;
+    if (!d_pts || !d_dist) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null device pointer");
+    if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
+    HIP_TRY(c, launch_nearest(c->tree, d_pts, nullptr, (uint32_t)n, d_dist, d_prim, nullptr, (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_nearest(sdfgpu_ctx* c, const float* pts, size_t n, float* out_dist, uint32_t* out_prim) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (n == 0) return SDFGPU_OK;
+    if (!pts || !out_dist) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null pointer");
+    for (size_t i = 0; i < n; ++i)
+        if (pts[4 * i + 3] != 1.0f) {
+            char b[96];
+            std::snprintf(b, sizeof b, "point %zu has w = %g (the path is defined for w = 1)", i, (double)pts[4 * i + 3]);
+            return set_err(c, SDFGPU_ERR_POINT_W, b);
+        }
+    if ((rc = reserve(c, c->in, n * 16)) || (rc = reserve(c, c->out_a, n * 4)) || (rc = reserve(c, c->out_b, n * 4))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->in.p, pts, n * 16, hipMemcpyHostToDevice, c->stream));
+    rc = sdfgpu_nearest_dev(c, (const float*)c->in.p, n, (float*)c->out_a.p, (uint32_t*)c->out_b.p, c->stream);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_dist, c->out_a.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_prim) HIP_TRY(c, hipMemcpyAsync(out_prim, c->out_b.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_nearest_stats_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, sdfgpu_stats* out) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!out) return SDFGPU_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    if (n == 0) return SDFGPU_OK;
+    if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
+    if ((rc = reserve(c, c->stats, sizeof(sdfgpu_stats))) || (rc = reserve(c, c->out_a, n * 4)) || (rc = reserve(c, c->out_b, n * 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, sizeof(sdfgpu_stats), c->stream));
+    HIP_TRY(c, launch_nearest(c->tree, d_pts, nullptr, (uint32_t)n, (float*)c->out_a.p, (uint32_t*)c->out_b.p,
+                              (sdfgpu_stats*)c->stats.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_knn_dev(sdfgpu_ctx* c, const float*, size_t, uint32_t, float*, uint32_t*, void*) {
+    return set_err(c, SDFGPU_ERR_INVALID_ARG, "kNN kernel not built yet");
+}
+int sdfgpu_knn(sdfgpu_ctx* c, const float*, size_t, uint32_t, float*, uint32_t*) {
+    return set_err(c, SDFGPU_ERR_INVALID_ARG, "kNN kernel not built yet");
+}
+
+int sdfgpu_render_tiles_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
+                            const sdfgpu_march_params* mp, uint32_t tile_first, uint32_t tile_stride,
+                            uint32_t tile_count, uint8_t* d_hit, float* d_depth, float* d_normal, uint32_t* d_prim,
+                            void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if ((rc = check_march(c, cam, w, h, mp))) return rc;
+    if (tile_count == 0) return SDFGPU_OK;
+    if (!d_hit) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null hit buffer");
+    const uint64_t tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
+    if (tile_stride == 0 || (uint64_t)tile_first + (uint64_t)(tile_count - 1) * tile_stride >= tiles)
+        return set_err(c, SDFGPU_ERR_INVALID_ARG, "tile range outside the frame");
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, tile_first, tile_stride, tile_count, false, d_hit, d_depth,
+                             d_normal, d_prim, nullptr, (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_untile_dev(sdfgpu_ctx* c, uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride,
+                      uint32_t tile_count, const uint8_t* t_hit, const float* t_depth, const float* t_normal,
+                      const uint32_t* t_prim, uint8_t* d_hit, float* d_depth, float* d_normal, uint32_t* d_prim,
+                      void* stream) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (w == 0 || h == 0 || tile_count == 0) return SDFGPU_OK;
+    if (!t_hit || !d_hit) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null hit buffer");
+    if ((d_depth && !t_depth) || (d_normal && !t_normal) || (d_prim && !t_prim))
+        return set_err(c, SDFGPU_ERR_INVALID_ARG, "destination plane without a source plane");
+    const uint64_t tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
+    if (tile_stride == 0 || (uint64_t)tile_first + (uint64_t)(tile_count - 1) * tile_stride >= tiles)
+        return set_err(c, SDFGPU_ERR_INVALID_ARG, "tile range outside the frame");
+    HIP_TRY(c, launch_untile(w, h, tile_first, tile_stride, tile_count, t_hit, t_depth, t_normal, t_prim, d_hit,
+                             d_depth, d_normal, d_prim, (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_render(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h, const sdfgpu_march_params* mp,
+                  uint8_t* hit, float* depth, float* normal, uint32_t* prim) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if ((rc = check_march(c, cam, w, h, mp))) return rc;
+    if (!hit) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null hit buffer");
+    const size_t np = (size_t)w * h;
+    if ((rc = reserve(c, c->out_a, np)) || (rc = reserve(c, c->out_b, np * 4)) || (rc = reserve(c, c->out_c, np * 12)) ||
+        (rc = reserve(c, c->out_d, np * 4)))
+        return rc;
+    const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, (uint8_t*)c->out_a.p, (float*)c->out_b.p,
+                             (float*)c->out_c.p, (uint32_t*)c->out_d.p, nullptr, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hit, c->out_a.p, np, hipMemcpyDeviceToHost, c->stream));
+    if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->out_b.p, np * 4, hipMemcpyDeviceToHost, c->stream));
+    if (normal) HIP_TRY(c, hipMemcpyAsync(normal, c->out_c.p, np * 12, hipMemcpyDeviceToHost, c->stream));
+    if (prim) HIP_TRY(c, hipMemcpyAsync(prim, c->out_d.p, np * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_render_stats(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
+                        const sdfgpu_march_params* mp, sdfgpu_stats* out) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if ((rc = check_march(c, cam, w, h, mp))) return rc;
+    if (!out) return SDFGPU_ERR_INVALID_ARG;
+    const size_t np = (size_t)w * h;
+    if ((rc = reserve(c, c->out_a, np)) || (rc = reserve(c, c->stats, sizeof(sdfgpu_stats)))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, sizeof(sdfgpu_stats), c->stream));
+    const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, (uint8_t*)c->out_a.p, nullptr, nullptr,
+                             nullptr, (sdfgpu_stats*)c->stats.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
+void sdfgpu_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y, uint32_t width,
+                           uint32_t height, sdfgpu_camera* out) {
+    double f[3], r[3], u[3];
+    double fl = 0, rl = 0;
+    for (int i = 0; i < 3; ++i) { f[i] = (double)target[i] - (double)eye[i]; fl += f[i] * f[i]; }
+    fl = std::sqrt(fl);
+    for (int i = 0; i < 3; ++i) f[i] /= fl;
+    // right = f x up, true up = right x f  (right-handed, image y grows downward)
+    r[0] = f[1] * up[2] - f[2] * up[1];
+    r[1] = f[2] * up[0] - f[0] * up[2];
+    r[2] = f[0] * up[1] - f[1] * up[0];
+    for (int i = 0; i < 3; ++i) rl += r[i] * r[i];
+    rl = std::sqrt(rl);
+    for (int i = 0; i < 3; ++i) r[i] /= rl;
+    u[0] = r[1] * f[2] - r[2] * f[1];
+    u[1] = r[2] * f[0] - r[0] * f[2];
+    u[2] = r[0] * f[1] - r[1] * f[0];
+    const double half_h = std::tan(0.5 * (double)fov_y);           // image plane at distance 1
+    const double half_w = half_h * (double)width / (double)height;
+    const double sx = 2.0 * half_w / (double)width, sy = 2.0 * half_h / (double)height;
+    for (int i = 0; i < 3; ++i) {
+        out->eye[i] = eye[i];
+        out->du[i] = (float)(r[i] * sx);
+        out->dv[i] = (float)(-u[i] * sy);
+        double o = (double)eye[i] + f[i] - r[i] * (half_w - 0.5 * sx) + u[i] * (half_h - 0.5 * sy);
+        out->origin[i] = (float)o;
+    }
+}
+
+}  // extern "C"

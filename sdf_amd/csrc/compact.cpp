@@ -1,0 +1,337 @@
+// compact.cpp -- validation of crate-format tree buffers and compaction into
+// the resident GPU tree (gpu_tree.hpp).  Host code, runs once per upload.
+//
+// What is validated here is exactly what the kernels rely on, so that a kernel
+// can never index out of bounds or loop forever (SURVEY 8b "Errors"): the
+// invariants ExpandedSdfNode::make_buffer establishes (sdf/src/node.rs:75-138,
+// SURVEY A.1) and the op codes faux_shader.rs:60-94 dispatches on.
+#include "gpu_tree.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace sdfgpu {
+namespace {
+
+struct Box3 {
+    double lo[3], hi[3];
+};
+
+struct Ctx {
+    const SdfOperationBlock* dt;
+    uint32_t n;
+    uint32_t bounds;
+    std::vector<uint32_t> prim_id;
+    std::vector<uint32_t> child0, child1;  // REF_NONE if absent (node indices)
+    CompactTree* out;
+    std::string* err;
+    uint32_t max_inner_depth = 0;
+};
+
+bool finite16(const float* m) {
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite(m[i])) return false;
+    return true;
+}
+
+bool is_identity(const float* m) {
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            if (m[4 * c + r] != (r == c ? 1.f : 0.f)) return false;
+    return true;
+}
+
+bool bottom_row_exact(const float* m) { return m[3] == 0.f && m[7] == 0.f && m[11] == 0.f && m[15] == 1.f; }
+
+bool rigid3(const float* m, double tol) {
+    // columns c of the 3x3: m[4c + r]
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double s = 0;
+            for (int r = 0; r < 3; ++r) s += (double)m[4 * a + r] * (double)m[4 * b + r];
+            if (std::fabs(s - (a == b ? 1.0 : 0.0)) > tol) return false;
+        }
+    return true;
+}
+
+float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+// World AABB of one primitive from its world->primitive transform.
+bool leaf_aabb(const SdfOperationBlock& b, Box3* box) {
+    const float* m = b.bounding_box.trans_inverse.m;
+    double A[3][3], I[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) A[r][c] = m[4 * c + r];
+    double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    if (!(std::fabs(det) > 1e-12)) return false;
+    double r = 1.0 / det;
+    I[0][0] = c00 * r; I[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * r; I[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * r;
+    I[1][0] = c01 * r; I[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * r; I[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * r;
+    I[2][0] = c02 * r; I[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * r; I[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * r;
+    double t[3] = {m[12], m[13], m[14]};
+    double ext[3], cen[3];
+    for (int i = 0; i < 3; ++i) {
+        cen[i] = -(I[i][0] * t[0] + I[i][1] * t[1] + I[i][2] * t[2]);
+        if (b.op_code == SDF_PRIM_SPHERE) {
+            double rad = std::fabs((double)b.op_specific.floats[0]);
+            ext[i] = rad * std::sqrt(I[i][0] * I[i][0] + I[i][1] * I[i][1] + I[i][2] * I[i][2]);
+        } else {
+            const float* h = b.op_specific.vec4s[0].v;
+            ext[i] = std::fabs(I[i][0]) * std::fabs((double)h[0]) + std::fabs(I[i][1]) * std::fabs((double)h[1]) +
+                     std::fabs(I[i][2]) * std::fabs((double)h[2]);
+        }
+        // outward padding: the leaf value the kernels compute carries the
+        // rounding of a 3x4 mat-vec at |coordinate| magnitude.
+        double pad = 1e-4 * ext[i] + 64.0 * (double)FLT_EPSILON * (std::fabs(cen[i]) + ext[i] + 1.0);
+        box->lo[i] = cen[i] - ext[i] - pad;
+        box->hi[i] = cen[i] + ext[i] + pad;
+    }
+    return true;
+}
+
+void fill_obb(const SdfBoundingBoxBlock& bb, float fi[12], float sc[3]) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) fi[4 * r + c] = bb.full_inverse.m[4 * c + r];
+    sc[0] = bb.scale.v[0]; sc[1] = bb.scale.v[1]; sc[2] = bb.scale.v[2];
+}
+
+// Returns the reference of node i in the compact tree and its box / depth.
+uint32_t emit(Ctx& c, uint32_t i, Box3* box, uint32_t* depth) {
+    const SdfOperationBlock& b = c.dt[i];
+    if (b.is_primitive) {
+        *depth = 0;
+        if (c.bounds == SDFGPU_BOUNDS_AABB) leaf_aabb(b, box);
+        return REF_LEAF | c.prim_id[i];
+    }
+    uint32_t k0 = c.child0[i], k1 = c.child1[i];
+    if (k1 == REF_NONE) return emit(c, k0, box, depth);  // 1-slot union: identity pass-through
+    uint32_t self = 0;
+    if (c.bounds == SDFGPU_BOUNDS_OBB) {
+        self = (uint32_t)c.out->inner_obb.size();
+        c.out->inner_obb.emplace_back();
+    } else {
+        self = (uint32_t)c.out->inner.size();
+        c.out->inner.emplace_back();
+    }
+    Box3 b0{}, b1{};
+    uint32_t d0 = 0, d1 = 0;
+    uint32_t r0 = emit(c, k0, &b0, &d0);
+    uint32_t r1 = emit(c, k1, &b1, &d1);
+    *depth = 1 + std::max(d0, d1);
+    if (c.bounds == SDFGPU_BOUNDS_OBB) {
+        GpuInnerObb& g = c.out->inner_obb[self];
+        std::memset(&g, 0, sizeof g);
+        fill_obb(c.dt[k0].bounding_box, g.fi0, g.sc0);
+        fill_obb(c.dt[k1].bounding_box, g.fi1, g.sc1);
+        g.ref0 = r0;
+        g.ref1 = r1;
+    } else {
+        GpuInner& g = c.out->inner[self];
+        std::memset(&g, 0, sizeof g);
+        for (int a = 0; a < 3; ++a) {
+            if (c.bounds == SDFGPU_BOUNDS_AABB) {
+                g.lo0[a] = round_down(b0.lo[a]); g.hi0[a] = round_up(b0.hi[a]);
+                g.lo1[a] = round_down(b1.lo[a]); g.hi1[a] = round_up(b1.hi[a]);
+                box->lo[a] = std::min(b0.lo[a], b1.lo[a]);
+                box->hi[a] = std::max(b0.hi[a], b1.hi[a]);
+            } else {  // NONE: boxes that contain everything -> nothing is ever pruned
+                g.lo0[a] = g.lo1[a] = -FLT_MAX;
+                g.hi0[a] = g.hi1[a] = FLT_MAX;
+            }
+        }
+        g.ref0 = r0;
+        g.ref1 = r1;
+    }
+    return self;
+}
+
+int fail(std::string* err, int code, const char* fmt, uint32_t a = 0, uint32_t b = 0) {
+    if (err) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, fmt, a, b);
+        *err = buf;
+    }
+    return code;
+}
+
+}  // namespace
+
+int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
+                 uint32_t layout, uint32_t bounds, CompactTree* out, std::string* err) {
+    *out = CompactTree();
+    if (layout != SDFGPU_LAYOUT_GLAM_SSE2)
+        return fail(err, SDFGPU_ERR_LAYOUT, "unsupported record layout %u (only glam SSE2: 624/224-byte records)", layout);
+    if (bounds > SDFGPU_BOUNDS_NONE) return fail(err, SDFGPU_ERR_INVALID_ARG, "unknown bounds mode %u", bounds);
+    out->info.n_nodes = n;
+    if (n == 0) {  // faux_shader.rs:104,207: empty buffer -> +inf
+        out->info.bounds = bounds == SDFGPU_BOUNDS_AUTO ? (uint32_t)SDFGPU_BOUNDS_AABB : bounds;
+        out->info.identity_inner = 1;
+        out->info.rigid_leaves = 1;
+        return SDFGPU_OK;
+    }
+    if (!dt || !ut) return fail(err, SDFGPU_ERR_INVALID_ARG, "null buffer pointer");
+    if (n > REF_INDEX) return fail(err, SDFGPU_ERR_TOO_LARGE, "buffer_len %u too large", n);
+
+    Ctx c;
+    c.dt = dt; c.n = n; c.out = out; c.err = err;
+    c.prim_id.assign(n, SDF_NO_PRIM);
+    c.child0.assign(n, REF_NONE);
+    c.child1.assign(n, REF_NONE);
+
+    // ---- structure: levels, len, child counts, op codes ----
+    if (dt[0].level != 1) return fail(err, SDFGPU_ERR_BAD_TREE, "root level is %u, expected 1", dt[0].level);
+    if (dt[0].len != n - 1) return fail(err, SDFGPU_ERR_BAD_TREE, "root len %u does not span buffer_len %u", dt[0].len, n);
+    uint32_t n_prims = 0, n_inner = 0, max_level = 0;
+    bool identity_inner = true, rigid = true, exact_rows = true;
+    float margin_T = 0.f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const SdfOperationBlock& b = dt[i];
+        if (b.level == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u has level 0", i);
+        if (b.level >= 255) return fail(err, SDFGPU_ERR_TOO_DEEP, "node %u at level %u (the reference stack holds 256 frames)", i, b.level);
+        if (b.is_primitive > 1 || b.parent_is_union > 1) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: bool field is not 0/1", i);
+        if ((uint64_t)i + b.len >= n) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: len %u runs past the buffer", i, b.len);
+        max_level = std::max(max_level, b.level);
+        const float* ti = b.bounding_box.trans_inverse.m;
+        if (!finite16(ti)) return fail(err, SDFGPU_ERR_NON_FINITE, "node %u: non-finite trans_inverse", i);
+        if (b.is_primitive) {
+            if (b.len != 0) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u has len %u", i, b.len);
+            if (b.op_code == SDF_PRIM_SPHERE) {
+                if (!std::isfinite(b.op_specific.floats[0])) return fail(err, SDFGPU_ERR_NON_FINITE, "primitive %u: non-finite radius", i);
+                margin_T = std::max(margin_T, std::fabs(b.op_specific.floats[0]));
+            } else if (b.op_code == SDF_PRIM_BOX) {
+                for (int a = 0; a < 3; ++a) {
+                    float h = b.op_specific.vec4s[0].v[a];
+                    if (!std::isfinite(h)) return fail(err, SDFGPU_ERR_NON_FINITE, "primitive %u: non-finite half extent", i);
+                    margin_T = std::max(margin_T, std::fabs(h));
+                }
+            } else {
+                return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported primitive op code: %u (node %u)", b.op_code, i);
+            }
+            if (!bottom_row_exact(ti)) exact_rows = false;
+            if (!rigid3(ti, 1e-4)) rigid = false;
+            c.prim_id[i] = n_prims++;
+        } else {
+            if (b.op_code != SDF_OP_UNION)
+                return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported downtree op code: %u (node %u)", b.op_code, i);
+            if (b.len == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "operation node %u has no children", i);
+            if (!is_identity(ti)) identity_inner = false;
+            ++n_inner;
+            uint32_t end = i + b.len, k = i + 1, cnt = 0;
+            while (k <= end) {
+                if (dt[k].level != b.level + 1)
+                    return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: child %u is not one level below", i, k);
+                if ((uint64_t)k + dt[k].len > end)
+                    return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: child %u overruns its parent", i, k);
+                if (cnt == 0) c.child0[i] = k;
+                else if (cnt == 1) c.child1[i] = k;
+                else return fail(err, SDFGPU_ERR_BAD_TREE, "node %u has more than two children (frames hold two, faux_shader.rs:14-15)", i);
+                ++cnt;
+                k += 1 + dt[k].len;
+            }
+        }
+    }
+    // ---- the uptree buffer must be the post-order of the same tree ----
+    {
+        std::vector<uint32_t> stack, post;
+        post.reserve(n);
+        // iterative post-order over (child0, child1)
+        std::vector<std::pair<uint32_t, uint8_t>> st;
+        st.emplace_back(0u, (uint8_t)0);
+        while (!st.empty()) {
+            auto& top = st.back();
+            uint32_t i = top.first;
+            if (top.second == 0) {
+                top.second = 1;
+                if (c.child0[i] != REF_NONE) { st.emplace_back(c.child0[i], (uint8_t)0); continue; }
+            }
+            if (st.back().second == 1) {
+                st.back().second = 2;
+                if (c.child1[i] != REF_NONE) { st.emplace_back(c.child1[i], (uint8_t)0); continue; }
+            }
+            post.push_back(i);
+            st.pop_back();
+        }
+        if (post.size() != n) return fail(err, SDFGPU_ERR_BAD_TREE, "tree does not cover the buffer");
+        for (uint32_t j = 0; j < n; ++j) {
+            const SdfOperationBlock& b = dt[post[j]];
+            if (ut[j].level != b.level || ut[j].op_code != b.op_code)
+                return fail(err, SDFGPU_ERR_BAD_TREE, "uptree block %u does not match downtree node %u", j, post[j]);
+        }
+    }
+    if (max_level - 1 > 63) return fail(err, SDFGPU_ERR_TOO_DEEP, "tree depth %u exceeds the 64-entry wave stack", max_level);
+
+    if (!identity_inner || !exact_rows)
+        return fail(err, SDFGPU_ERR_UNSUPPORTED_OP,
+                    "tree needs the general path (non-identity internal trans_inverse or projective leaf rows), not built yet");
+
+    uint32_t mode = bounds;
+    if (mode == SDFGPU_BOUNDS_AUTO) mode = rigid ? SDFGPU_BOUNDS_AABB : SDFGPU_BOUNDS_NONE;
+    if (mode == SDFGPU_BOUNDS_AABB && !rigid)
+        return fail(err, SDFGPU_ERR_BAD_TREE, "AABB bounds need rigid leaf transforms (trans_inverse is not orthonormal)");
+    if (mode == SDFGPU_BOUNDS_OBB) {
+        for (uint32_t i = 0; i < n; ++i) {
+            const SdfBoundingBoxBlock& bb = dt[i].bounding_box;
+            if (!finite16(bb.full_inverse.m) || !std::isfinite(bb.scale.v[0]) || !std::isfinite(bb.scale.v[1]) ||
+                !std::isfinite(bb.scale.v[2]))
+                return fail(err, SDFGPU_ERR_NON_FINITE, "node %u: non-finite bounding box", i);
+            if (!bottom_row_exact(bb.full_inverse.m) || bb.scale.v[3] != 0.f)
+                return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: OBB bounds need an affine full_inverse and scale.w == 0", i);
+        }
+    }
+    c.bounds = mode;
+
+    // ---- leaves, in primitive-id order ----
+    out->leaves.resize(n_prims);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!dt[i].is_primitive) continue;
+        GpuLeaf& L = out->leaves[c.prim_id[i]];
+        std::memset(&L, 0, sizeof L);
+        const float* m = dt[i].bounding_box.trans_inverse.m;
+        for (int r = 0; r < 3; ++r)
+            for (int col = 0; col < 4; ++col) L.m[4 * r + col] = m[4 * col + r];
+        margin_T = std::max(margin_T, std::fabs(m[12]) + std::fabs(m[13]) + std::fabs(m[14]));
+        L.kind = dt[i].op_code;
+        if (L.kind == SDF_PRIM_SPHERE) {
+            L.param[0] = dt[i].op_specific.floats[0];
+        } else {
+            for (int a = 0; a < 3; ++a) L.param[a] = dt[i].op_specific.vec4s[0].v[a];
+        }
+    }
+    if (mode == SDFGPU_BOUNDS_OBB) out->inner_obb.reserve(n_inner);
+    else out->inner.reserve(n_inner);
+    Box3 root{};
+    uint32_t depth = 0;
+    out->root_ref = emit(c, 0, &root, &depth);
+    out->stack_depth = std::max(1u, depth);
+    out->margin_T = margin_T;
+
+    sdfgpu_tree_info& info = out->info;
+    info.n_prims = n_prims;
+    info.n_inner = (uint32_t)(mode == SDFGPU_BOUNDS_OBB ? out->inner_obb.size() : out->inner.size());
+    info.max_level = max_level;
+    info.bounds = mode;
+    info.identity_inner = identity_inner ? 1 : 0;
+    info.rigid_leaves = rigid ? 1 : 0;
+    info.device_bytes = out->leaves.size() * sizeof(GpuLeaf) + out->inner.size() * sizeof(GpuInner) +
+                        out->inner_obb.size() * sizeof(GpuInnerObb);
+    if (mode == SDFGPU_BOUNDS_AABB)
+        for (int a = 0; a < 3; ++a) { info.scene_lo[a] = (float)root.lo[a]; info.scene_hi[a] = (float)root.hi[a]; }
+    return SDFGPU_OK;
+}
+
+}  // namespace sdfgpu

@@ -1,0 +1,70 @@
+// gpu_tree.hpp -- the resident (compact) tree the kernels traverse, and the
+// host-side compaction that produces it from the crate's 624+224-byte records.
+//
+// The crate streams 848 B per node (component.rs:27-60).  The kernels need,
+// per primitive, a 3x4 point transform + 3 parameters (64 B) and, per internal
+// node, the bounds of its two children + two child references (64 B in AABB
+// mode, 128 B in OBB mode).  Every record is a whole number of 64-byte lines
+// and is fetched with wave-uniform scalar loads.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sdf_blocks.h"
+#include "../../include/sdfgpu.h"
+
+namespace sdfgpu {
+
+constexpr uint32_t REF_LEAF = 0x80000000u;  // child reference: bit 31 = primitive
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // empty tree / absent child
+constexpr uint32_t REF_INDEX = 0x7FFFFFFFu;
+
+// One primitive.  m = rows of the leaf's trans_inverse (world -> primitive
+// frame): row r = m[4r .. 4r+3], translation in m[4r+3].  index in the array
+// = primitive id = pre-order ordinal.
+struct alignas(64) GpuLeaf {
+    float m[12];
+    float param[3];   // sphere: radius,0,0   box: half extents
+    uint32_t kind;    // SDF_PRIM_SPHERE / SDF_PRIM_BOX
+};
+static_assert(sizeof(GpuLeaf) == 64, "GpuLeaf is one 64-byte line");
+
+// Internal node, AABB mode: world-space boxes of both children.
+struct alignas(64) GpuInner {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t ref0, ref1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(GpuInner) == 64, "GpuInner is one 64-byte line");
+
+// Internal node, OBB mode: the buffer's own boxes (full_inverse rows + scale),
+// i.e. the operands of MINDIST, faux_shader.rs:54-58.
+struct alignas(64) GpuInnerObb {
+    float fi0[12];
+    float sc0[3];
+    uint32_t ref0;
+    float fi1[12];
+    float sc1[3];
+    uint32_t ref1;
+};
+static_assert(sizeof(GpuInnerObb) == 128, "GpuInnerObb is two 64-byte lines");
+
+struct CompactTree {
+    std::vector<GpuLeaf> leaves;
+    std::vector<GpuInner> inner;        // AABB mode
+    std::vector<GpuInnerObb> inner_obb; // OBB mode
+    uint32_t root_ref = REF_NONE;
+    uint32_t stack_depth = 1;           // pending far children never exceed this
+    float margin_T = 0.f;               // scene term of the prune margin
+    sdfgpu_tree_info info{};
+};
+
+// Validate the crate-format buffers and build the compact tree.  Returns an
+// sdfgpu_status; on failure `err` has the detail.  Pure host code (testable
+// without a GPU through sdfgpu_compact_host).
+int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
+                 uint32_t layout, uint32_t bounds, CompactTree* out, std::string* err);
+
+}  // namespace sdfgpu

@@ -1,0 +1,35 @@
+// kernels.hpp -- launch interface between the C ABI (api.cpp) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/sdfgpu.h"
+#include "gpu_tree.hpp"
+
+namespace sdfgpu {
+
+// Device-resident compact tree (pointers into HBM).
+struct DeviceTree {
+    GpuLeaf* leaf = nullptr;
+    GpuInner* inner = nullptr;
+    GpuInnerObb* inner_obb = nullptr;
+    uint32_t root_ref = REF_NONE;
+    uint32_t stack_depth = 1;
+    uint32_t bounds = SDFGPU_BOUNDS_AABB;
+    float margin_T = 0.f;
+};
+
+// st != nullptr selects the counting instantiation of the same kernel.
+hipError_t launch_nearest(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n,
+                          float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s);
+
+hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
+                         const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
+                         bool row_major, uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st,
+                         hipStream_t s);
+
+hipError_t launch_untile(uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
+                         const uint8_t* t_hit, const float* t_depth, const float* t_normal, const uint32_t* t_prim,
+                         uint8_t* hit, float* depth, float* normal, uint32_t* prim, hipStream_t s);
+
+}  // namespace sdfgpu

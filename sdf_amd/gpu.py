@@ -1,0 +1,154 @@
+"""Thin Python view of the C ABI in include/sdfgpu.h (one context per GPU).
+
+Everything here ends in a call into libsdfgpu.so; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .scene import SdfTreeBuffer
+
+
+class SdfGpuError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"sdfgpu status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def camera_look_at(eye, target, up, fov_y, width, height):
+    """Pinhole camera POD (geometry of src/main__.rs:261-264)."""
+    cam = _ffi.Camera()
+    e, t, u = (np.asarray(v, dtype=np.float32) for v in (eye, target, up))
+    _ffi.load_library().sdfgpu_camera_look_at(_ffi.fptr(e), _ffi.fptr(t), _ffi.fptr(u), fov_y, width, height, C.byref(cam))
+    return cam
+
+
+def march_params(max_steps=128, eps_hit=1e-3, t_min=0.0, t_max=1e3, normal_h=1e-4):
+    return _ffi.MarchParams(max_steps, eps_hit, t_min, t_max, normal_h, 0)
+
+
+def compact_host(buf, bounds=_ffi.BOUNDS_AUTO, layout=_ffi.LAYOUT_GLAM_SSE2):
+    """Validation + compaction only (no GPU): returns (status, TreeInfo, message)."""
+    lib = _ffi.load_library()
+    info = _ffi.TreeInfo()
+    err = C.create_string_buffer(512)
+    rc = lib.sdfgpu_compact_host(
+        buf.downtree_buffer.ctypes.data if buf.buffer_len else None,
+        buf.uptree_buffer.ctypes.data if buf.buffer_len else None,
+        buf.buffer_len, layout, bounds, C.byref(info), err, 512,
+    )
+    return rc, info, err.value.decode()
+
+
+class SdfGpu:
+    """sdfgpu_ctx: owns the resident tree of one GPU."""
+
+    def __init__(self, device=0):
+        self._lib = _ffi.load_library()
+        h = C.c_void_p()
+        rc = self._lib.sdfgpu_create(device, C.byref(h))
+        if rc != 0:
+            raise SdfGpuError(rc, f"sdfgpu_create(device={device}) failed: " + self._lib.sdfgpu_status_string(rc).decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdfgpu_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdfGpuError(rc, self._lib.sdfgpu_last_error(self._h).decode())
+
+    def sync(self):
+        self._check(self._lib.sdfgpu_sync(self._h))
+
+    # ---- tree -----------------------------------------------------------
+    def upload_tree(self, buf: SdfTreeBuffer, bounds=_ffi.BOUNDS_AUTO, layout=_ffi.LAYOUT_GLAM_SSE2):
+        n = buf.buffer_len
+        self._check(
+            self._lib.sdfgpu_upload_tree(
+                self._h,
+                buf.downtree_buffer.ctypes.data if n else None,
+                buf.uptree_buffer.ctypes.data if n else None,
+                n, layout, bounds,
+            )
+        )
+        return self.info()
+
+    def info(self):
+        info = _ffi.TreeInfo()
+        self._check(self._lib.sdfgpu_tree_info_get(self._h, C.byref(info)))
+        return info
+
+    # ---- nearest ----------------------------------------------------------
+    def nearest(self, pts_xyzw):
+        """faux_shader::nearest_neighbor for an (n,4) float32 array -> (dist, prim)."""
+        p = np.ascontiguousarray(pts_xyzw, dtype=np.float32).reshape(-1, 4)
+        n = p.shape[0]
+        dist = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32)
+        self._check(self._lib.sdfgpu_nearest(self._h, p.ctypes.data, n, dist.ctypes.data, prim.ctypes.data))
+        return dist, prim
+
+    def nearest_dev(self, d_pts, n, d_dist, d_prim, stream=0):
+        self._check(self._lib.sdfgpu_nearest_dev(self._h, d_pts, n, d_dist, d_prim, stream))
+
+    def nearest_stats_dev(self, d_pts, n):
+        st = _ffi.Stats()
+        self._check(self._lib.sdfgpu_nearest_stats_dev(self._h, d_pts, n, C.byref(st)))
+        return st.as_dict()
+
+    def knn(self, pts_xyzw, k):
+        p = np.ascontiguousarray(pts_xyzw, dtype=np.float32).reshape(-1, 4)
+        n = p.shape[0]
+        dist = np.empty((n, k), np.float32)
+        prim = np.empty((n, k), np.uint32)
+        self._check(self._lib.sdfgpu_knn(self._h, p.ctypes.data, n, k, dist.ctypes.data, prim.ctypes.data))
+        return dist, prim
+
+    def knn_dev(self, d_pts, n, k, d_dist, d_prim, stream=0):
+        self._check(self._lib.sdfgpu_knn_dev(self._h, d_pts, n, k, d_dist, d_prim, stream))
+
+    # ---- sphere trace -----------------------------------------------------
+    def render(self, cam, width, height, mp):
+        np_ = width * height
+        hit = np.empty(np_, np.uint8)
+        depth = np.empty(np_, np.float32)
+        normal = np.empty((np_, 3), np.float32)
+        prim = np.empty(np_, np.uint32)
+        self._check(
+            self._lib.sdfgpu_render(
+                self._h, C.byref(cam), width, height, C.byref(mp),
+                hit.ctypes.data, depth.ctypes.data, normal.ctypes.data, prim.ctypes.data,
+            )
+        )
+        return {"hit": hit, "depth": depth, "normal": normal, "prim": prim}
+
+    def render_tiles_dev(self, cam, width, height, mp, tile_first, tile_stride, tile_count,
+                         d_hit, d_depth, d_normal, d_prim, stream=0):
+        self._check(
+            self._lib.sdfgpu_render_tiles_dev(
+                self._h, C.byref(cam), width, height, C.byref(mp), tile_first, tile_stride, tile_count,
+                d_hit, d_depth, d_normal, d_prim, stream,
+            )
+        )
+
+    def untile_dev(self, width, height, tile_first, tile_stride, tile_count,
+                   t_hit, t_depth, t_normal, t_prim, d_hit, d_depth, d_normal, d_prim, stream=0):
+        self._check(
+            self._lib.sdfgpu_untile_dev(
+                self._h, width, height, tile_first, tile_stride, tile_count,
+                t_hit, t_depth, t_normal, t_prim, d_hit, d_depth, d_normal, d_prim, stream,
+            )
+        )
+
+    def render_stats(self, cam, width, height, mp):
+        st = _ffi.Stats()
+        self._check(self._lib.sdfgpu_render_stats(self._h, C.byref(cam), width, height, C.byref(mp), C.byref(st)))
+        return st.as_dict()

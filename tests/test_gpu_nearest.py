@@ -1,0 +1,104 @@
+"""GPU parity: sdfgpu_nearest (K1) against the CPU restatement of
+faux_shader::nearest_neighbor (sdf/src/faux_shader.rs:96-208).
+
+Bar: distances bit-exact (stronger than the 1e-5 relative the north star
+asks), primitive indices bit-exact.  All calls go through the C ABI.
+"""
+import numpy as np
+import pytest
+
+import sdf_amd as S
+from oracle import oracle as O
+from conftest import bits, make_points
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(gpu, buf, pts, bounds, mode=O.MODE_EXHAUSTIVE):
+    gpu.upload_tree(buf, bounds=bounds)
+    d, i = gpu.nearest(pts)
+    d0, i0 = O.nearest(buf, pts, mode)
+    assert np.array_equal(bits(d), bits(d0)), f"distance bits differ at {np.flatnonzero(bits(d) != bits(d0))[:8]}"
+    assert np.array_equal(i, i0), f"indices differ at {np.flatnonzero(i != i0)[:8]}"
+
+
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE])
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 257, 1000])
+def test_nearest_matches_oracle(gpu, n, bounds):
+    buf = S.random_scene_buffer(n, 0x5DF00000 + n)
+    L = S.default_extent(n)
+    pts = make_points(4096 if n < 1000 else 16384, L, seed=n)
+    _check(gpu, buf, pts, bounds)
+
+
+def test_nearest_matches_faux_as_written(gpu):
+    # the literal walk (with the reference's own leaf-pair prune) agrees with
+    # the exhaustive one on consistent buffers, and so does the GPU
+    buf = S.random_scene_buffer(300, 77)
+    pts = make_points(4096, S.default_extent(300), seed=5)
+    _check(gpu, buf, pts, S.BOUNDS_AUTO, mode=O.MODE_FAUX)
+
+
+def test_config1_64k_points_1k_prims(gpu):
+    # BASELINE config 1: 1k primitives, seed 0x5DF00001, 64 Ki points
+    buf = S.random_scene_buffer(1000, 0x5DF00001)
+    pts = make_points(65536, S.default_extent(1000), seed=0x5DF00001)
+    gpu.upload_tree(buf)
+    d, i = gpu.nearest(pts)
+    d0, i0 = O.nearest(buf, pts, O.MODE_TUNED, threads=8)
+    assert np.array_equal(bits(d), bits(d0))
+    assert np.array_equal(i, i0)
+
+
+def test_empty_tree(gpu):
+    gpu.upload_tree(S.SdfTreeBuffer.make_empty())
+    d, i = gpu.nearest(make_points(100, 10.0, 1))
+    assert np.all(np.isposinf(d)) and np.all(i == S.NO_PRIM)   # faux_shader.rs:104,207
+
+
+def test_ragged_point_counts(gpu):
+    buf = S.random_scene_buffer(50, 9)
+    for n in (1, 63, 64, 65, 255, 256, 257, 1000):
+        _check(gpu, buf, make_points(n, S.default_extent(50), seed=n), S.BOUNDS_AUTO)
+
+
+def test_points_inside_primitives_and_far_away(gpu):
+    buf = S.random_scene_buffer(200, 31)
+    L = S.default_extent(200)
+    near = make_points(4096, L, seed=3, scale=0.3)      # many inside / close
+    far = make_points(4096, L, seed=4, scale=40.0)      # far outside the scene
+    for b in (S.BOUNDS_AABB, S.BOUNDS_OBB):
+        _check(gpu, buf, near, b)
+        _check(gpu, buf, far, b)
+
+
+def test_duplicate_primitive_tie_goes_to_later(gpu):
+    # two identical spheres: the reference's min is `if a < b {a} else {b}`
+    # (faux_shader.rs:27-29) so the later one in pre-order wins
+    t = S.Transform.from_translation((1.0, 2.0, 3.0))
+    b = (S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(t).operation(S.SdfUnion(0.0))
+         .with_(S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(t))
+         .with_(S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(S.Transform.from_translation((30.0, 0, 0)))))
+    buf = b.finalize().expanded().make_buffer()
+    pts = make_points(2048, 20.0, seed=8)
+    _check(gpu, buf, pts, S.BOUNDS_AABB, mode=O.MODE_FAUX)
+    _check(gpu, buf, pts, S.BOUNDS_OBB, mode=O.MODE_EXHAUSTIVE)
+    gpu.upload_tree(buf)
+    d, i = gpu.nearest(pts)
+    dt = buf.downtree_buffer
+    # the two coincident spheres are two of the three primitives; find them
+    prim_nodes = np.flatnonzero(dt["is_primitive"])
+    tr = dt["bounding_box"]["trans_inverse"][prim_nodes][:, 12:15]
+    same = [k for k in range(3) if np.allclose(tr[k], [-1, -2, -3])]
+    assert len(same) == 2
+    near_dup = np.isin(i, same)
+    assert near_dup.any() and np.all(i[near_dup] == max(same))
+
+
+def test_w_not_one_is_rejected(gpu):
+    gpu.upload_tree(S.random_scene_buffer(4, 1))
+    p = make_points(8, 10.0, 1)
+    p[3, 3] = 0.5
+    with pytest.raises(S.SdfGpuError) as e:
+        gpu.nearest(p)
+    assert e.value.status == S._ffi.ERR_POINT_W
