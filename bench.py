@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the nearest-primitive / sphere-trace path.
+
+Workload (BASELINE.json metric: "Mrays/s ... 1080p 10k-primitive scene"):
+config 3 = one 1920x1080 sphere-traced frame with normals over the 10k
+primitive synthetic scene (seed 0x5DF00003).  A "step" is one full frame.
+
+  N = 1 : one sdfgpu_render_dev launch per step.
+  N > 1 : the frame's 8x8 tiles are dealt round-robin to the ranks (rank r
+          renders tiles r, r+N, ...), the tile-compact planes are packed and
+          all-gathered over RCCL, rank 0 scatters them into the frame.  The
+          total work per step is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  `value` = rays (pixels) per second, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import sdf_amd as S  # noqa: E402
+from sdf_amd import partition as P  # noqa: E402
+from sdf_amd import workloads as W  # noqa: E402
+
+VALU_PEAK_UNFUSED_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op per lane-issue
+VALU_PEAK_FMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)" (counts FMA as 2)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE config (2, 3 or 4 are frames)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget of the baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(buf, cam, mp, w, h, budget_s):
+    """Oracle timed on this host's cores on a strided sample of the same frame,
+    sized by a short pilot so that the leg costs about `budget_s` seconds."""
+    from oracle import oracle as O
+
+    threads = max(1, min(O.hardware_threads(), len(os.sched_getaffinity(0))))
+    npix = w * h
+
+    def run(mode, cnt):
+        stride = max(1, npix // cnt)
+        cnt = min(cnt, (npix + stride - 1) // stride)
+        t0 = time.perf_counter()
+        O.render(buf, cam, w, h, mp, mode=mode, threads=threads, pix_first=0, pix_count=cnt, pix_stride=stride)
+        return cnt, stride, time.perf_counter() - t0
+
+    def sized(mode, pilot, share):
+        cnt, _, t = run(mode, pilot)
+        want = int(min(npix, max(pilot, cnt / max(t, 1e-6) * budget_s * share)))
+        return run(mode, want)
+
+    cnt, stride, t = sized(O.MODE_TUNED, 4096, 0.6)
+    out = {
+        "value": cnt / t / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{cnt} rays (every {stride}th pixel of the same frame), oracle_render MODE_TUNED "
+                  f"(C++ restatement, best-so-far pruning), {threads} threads, {t:.2f} s",
+    }
+    cnt_f, stride_f, t_f = sized(O.MODE_FAUX_FAITHFUL, 128, 0.4)
+    out["faithful_value"] = cnt_f / t_f / 1e6
+    out["faithful_sample"] = (f"{cnt_f} rays (every {stride_f}th pixel), faux_shader::nearest_neighbor as written "
+                              f"(O(N) walk, 256-frame allocation per query), {threads} threads, {t_f:.2f} s")
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        a.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    wl = W.CONFIGS[a.config]
+    w, h = a.width or wl.width, a.height or wl.height
+    buf = W.scene(wl)
+    cam, mp = W.camera(wl, w, h), W.march(wl)
+    bounds = {"auto": S.BOUNDS_AUTO, "aabb": S.BOUNDS_AABB, "obb": S.BOUNDS_OBB, "none": S.BOUNDS_NONE}[a.bounds]
+    gpu = S.SdfGpu(local_rank)
+    info = gpu.upload_tree(buf, bounds=bounds)
+
+    npix = w * h
+    tiles = P.n_tiles(w, h)
+    stream = torch.cuda.current_stream().cuda_stream
+    o_hit = torch.empty(npix, dtype=torch.uint8, device=dev)
+    o_depth = torch.empty(npix, dtype=torch.float32, device=dev)
+    o_normal = torch.empty(npix * 3, dtype=torch.float32, device=dev)
+    o_prim = torch.empty(npix, dtype=torch.int32, device=dev)
+
+    if world == 1:
+        def step():
+            gpu.render_dev(cam, w, h, mp, o_hit.data_ptr(), o_depth.data_ptr(), o_normal.data_ptr(),
+                           o_prim.data_ptr(), stream)
+    else:
+        first, stride, cnt = P.rank_tiles(rank, world, tiles)
+        nbytes = P.packed_bytes(world, tiles)
+        # one packed byte buffer per rank: [depth f32 | normal 3xf32 | prim u32 | hit u8]
+        mine = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+        m_hit, m_depth, m_normal, m_prim = P.planes(mine, world, tiles)
+
+        def step():
+            gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, m_hit.data_ptr(), m_depth.data_ptr(),
+                                 m_normal.data_ptr(), m_prim.data_ptr(), stream)
+            dist.all_gather_into_tensor(gathered, mine)
+            if rank == 0:
+                for r in range(world):
+                    g_hit, g_depth, g_normal, g_prim = P.planes(gathered[r * nbytes: (r + 1) * nbytes], world, tiles)
+                    rf, rs, rc = P.rank_tiles(r, world, tiles)
+                    gpu.untile_dev(w, h, rf, rs, rc, g_hit.data_ptr(), g_depth.data_ptr(),
+                                   g_normal.data_ptr(), g_prim.data_ptr(), o_hit.data_ptr(), o_depth.data_ptr(),
+                                   o_normal.data_ptr(), o_prim.data_ptr(), stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    # kernel-only durations of the dominant kernel, HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        if world == 1:
+            ev[k][0].record()
+            step()
+            ev[k][1].record()
+        else:
+            step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    line = None
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        value = npix * a.steps / elapsed / 1e6
+        hit_frac = float(o_hit.float().mean().item())
+        line = {
+            "metric": "Mrays/s, sphere trace + normals",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": wl.name,
+                "width": w, "height": h, "n_prims": wl.n_prims, "seed": hex(wl.seed),
+                "tree_nodes": int(info.n_nodes), "tree_levels": int(info.max_level),
+                "bounds": {1: "aabb", 2: "obb", 3: "none"}[int(info.bounds)],
+                "tree_bytes_hbm": int(info.device_bytes),
+                "max_steps": int(mp.max_steps), "eps_hit": float(mp.eps_hit), "t_max": float(mp.t_max),
+                "normal_h": float(mp.normal_h),
+                "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL all-gather",
+                "hit_fraction": hit_frac,
+            },
+        }
+        if world == 1:
+            kms = [s.elapsed_time(e) for s, e in ev]
+            k_avg = float(np.mean(kms))
+            st = gpu.render_stats(cam, w, h, mp)
+            flops = W.algorithmic_flops(st)
+            achieved = flops / (k_avg * 1e-3) / 1e12
+            bytes_alg = npix * 21 + int(info.device_bytes)
+            line["roofline"] = {
+                "bound": "valu",
+                "achieved": achieved,
+                "peak": VALU_PEAK_UNFUSED_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / VALU_PEAK_UNFUSED_TFLOPS,
+                "traffic": None,
+                "kernel": "render_kernel<AABB>",
+                "kernel_ms_avg": k_avg,
+                "algorithmic_flops_per_launch": flops,
+                "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS,
+                "hbm": {"algorithmic_bytes_per_launch": bytes_alg,
+                        "achieved_GBs": bytes_alg / (k_avg * 1e-3) / 1e9,
+                        "peak_GBs": HBM_PEAK_GBS,
+                        "frac": bytes_alg / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "note": "fp32 VALU-bound tree walk, no dense contraction (no MFMA); leaf arithmetic must stay "
+                        "unfused for bit parity so the ceiling is one op per lane-issue (78.6 TFLOP/s), not the "
+                        "157.3 TFLOP/s FMA figure",
+            }
+            line["work"] = {
+                "steps_per_ray": st["steps"] / max(1, st["rays"]),
+                "inner_visits_per_query": st["inner_visits"] / max(1, st["queries"]),
+                "leaf_evals_per_query": (st["sphere_evals"] + st["box_evals"]) / max(1, st["queries"]),
+                "wave_inner_visits": st["wave_inner"], "wave_leaf_visits": st["wave_leaf"],
+                "queries": st["queries"],
+            }
+            if not a.no_cpu:
+                line["cpu_baseline"] = cpu_baseline(buf, cam, mp, w, h, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,26 +25,26 @@
 #include <stdint.h>
 
 #ifdef __cplusplus
-#define SDF_ALIGNAS(n) alignas(n)
 #define SDF_STATIC_ASSERT(c, m) static_assert(c, m)
 #else
-#define SDF_ALIGNAS(n) _Alignas(n)
 #define SDF_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
+/* 16-byte alignment of the TYPE (C11 _Alignas cannot be put on a struct tag) */
+#define SDF_ALIGN16 __attribute__((aligned(16)))
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* glam::Vec4 (SSE2): 4 x f32, align 16. */
-typedef struct SDF_ALIGNAS(16) SdfVec4 {
+typedef struct SdfVec4 {
     float v[4]; /* x y z w */
-} SdfVec4;
+} SDF_ALIGN16 SdfVec4;
 
 /* glam::Mat4 (SSE2): 4 columns of Vec4, column-major: m[4*col + row]. */
-typedef struct SDF_ALIGNAS(16) SdfMat4 {
+typedef struct SdfMat4 {
     float m[16];
-} SdfMat4;
+} SDF_ALIGN16 SdfMat4;
 
 /* component.rs:11-17 */
 typedef struct SdfOpSpecificBlock {

@@ -170,6 +170,11 @@ int sdfgpu_render(sdfgpu_ctx* ctx, const sdfgpu_camera* cam, uint32_t width,
                   uint32_t height, const sdfgpu_march_params* mp, uint8_t* hit,
                   float* depth, float* normal_xyz, uint32_t* prim);
 
+/* Full frame, device pointers, row-major planes, asynchronous on hip_stream. */
+int sdfgpu_render_dev(sdfgpu_ctx* ctx, const sdfgpu_camera* cam, uint32_t width,
+                      uint32_t height, const sdfgpu_march_params* mp, uint8_t* d_hit,
+                      float* d_depth, float* d_normal_xyz, uint32_t* d_prim, void* hip_stream);
+
 /* Tile-range form for the framebuffer partitioner.  The frame is cut into
  * 8x8-pixel tiles numbered row-major; this call renders tiles
  * tile_first, tile_first + tile_stride, ... (tile_count of them) and writes

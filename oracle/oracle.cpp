@@ -447,13 +447,13 @@ int oracle_bounds(const SdfOperationBlock* dt, uint32_t n, uint32_t node, const 
 }
 
 // Sphere trace + normals (DESIGN.md "march loop"; normals follow
-// src/main__.rs:151-161).  Pixels [pix_first, pix_first + pix_count) of the
-// row-major frame are rendered (a bounded sample for the CPU baseline).
+// src/main__.rs:151-161).  Pixels pix_first + k*pix_stride, k < pix_count, of
+// the row-major frame are rendered (a bounded sample for the CPU baseline).
 // out_steps may be NULL.
 int oracle_render(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
                   const sdfgpu_camera* cam, uint32_t width, uint32_t height,
                   const sdfgpu_march_params* mp, int mode, int threads, size_t pix_first,
-                  size_t pix_count, uint8_t* hit, float* depth, float* normal_xyz, uint32_t* prim,
+                  size_t pix_stride, size_t pix_count, uint8_t* hit, float* depth, float* normal_xyz, uint32_t* prim,
                   uint32_t* out_steps) {
     Tree t;
     int rc = build_tree(t, dt, ut, n);
@@ -463,7 +463,7 @@ int oracle_render(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut
         std::vector<Frame> stack(256);
         std::memset(stack.data(), 0, sizeof(Frame) * 256);
         for (size_t k = a; k < b; ++k) {
-            size_t pix = pix_first + k;
+            size_t pix = pix_first + k * pix_stride;
             float fx = (float)(uint32_t)(pix % width), fy = (float)(uint32_t)(pix / width);
             float dir[3], o[3];
             float pw[3];

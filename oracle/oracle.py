@@ -84,17 +84,17 @@ def bounds(buf, node, pts_xyzw):
     return lo, hi
 
 
-def render(buf, cam, width, height, mp, mode=MODE_TUNED, threads=1, pix_first=0, pix_count=None):
+def render(buf, cam, width, height, mp, mode=MODE_TUNED, threads=1, pix_first=0, pix_count=None, pix_stride=1):
     """cam / mp: the ctypes PODs of sdf_amd._ffi (plain data, same layout as include/sdfgpu.h)."""
     if pix_count is None:
-        pix_count = width * height - pix_first
+        pix_count = (width * height - pix_first + pix_stride - 1) // pix_stride
     hit = np.empty(pix_count, np.uint8)
     depth = np.empty(pix_count, np.float32)
     normal = np.empty((pix_count, 3), np.float32)
     prim = np.empty(pix_count, np.uint32)
     steps = np.empty(pix_count, np.uint32)
     rc = lib().oracle_render(*_tree_args(buf), C.byref(cam), C.c_uint32(width), C.c_uint32(height), C.byref(mp),
-                             C.c_int(mode), C.c_int(threads), C.c_size_t(pix_first), C.c_size_t(pix_count),
+                             C.c_int(mode), C.c_int(threads), C.c_size_t(pix_first), C.c_size_t(pix_stride), C.c_size_t(pix_count),
                              C.c_void_p(hit.ctypes.data), C.c_void_p(depth.ctypes.data),
                              C.c_void_p(normal.ctypes.data), C.c_void_p(prim.ctypes.data),
                              C.c_void_p(steps.ctypes.data))

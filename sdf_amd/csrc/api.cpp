@@ -263,6 +263,18 @@ int sdfgpu_render_tiles_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w,
     return SDFGPU_OK;
 }
 
+int sdfgpu_render_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h, const sdfgpu_march_params* mp,
+                      uint8_t* d_hit, float* d_depth, float* d_normal, uint32_t* d_prim, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if ((rc = check_march(c, cam, w, h, mp))) return rc;
+    if (!d_hit) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null hit buffer");
+    const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, d_hit, d_depth, d_normal, d_prim, nullptr,
+                             (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
 int sdfgpu_untile_dev(sdfgpu_ctx* c, uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride,
                       uint32_t tile_count, const uint8_t* t_hit, const float* t_depth, const float* t_normal,
                       const uint32_t* t_prim, uint8_t* d_hit, float* d_depth, float* d_normal, uint32_t* d_prim,

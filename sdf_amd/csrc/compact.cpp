@@ -200,9 +200,12 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     bool identity_inner = true, rigid = true, exact_rows = true;
     float margin_T = 0.f;
     for (uint32_t i = 0; i < n; ++i) {
+        if (dt[i].level == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u has level 0", i);
+        if (dt[i].level >= 255)
+            return fail(err, SDFGPU_ERR_TOO_DEEP, "node %u at level %u (the reference stack holds 256 frames)", i, dt[i].level);
+    }
+    for (uint32_t i = 0; i < n; ++i) {
         const SdfOperationBlock& b = dt[i];
-        if (b.level == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u has level 0", i);
-        if (b.level >= 255) return fail(err, SDFGPU_ERR_TOO_DEEP, "node %u at level %u (the reference stack holds 256 frames)", i, b.level);
         if (b.is_primitive > 1 || b.parent_is_union > 1) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: bool field is not 0/1", i);
         if ((uint64_t)i + b.len >= n) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: len %u runs past the buffer", i, b.len);
         max_level = std::max(max_level, b.level);

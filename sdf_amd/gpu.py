@@ -130,6 +130,13 @@ class SdfGpu:
         )
         return {"hit": hit, "depth": depth, "normal": normal, "prim": prim}
 
+    def render_dev(self, cam, width, height, mp, d_hit, d_depth, d_normal, d_prim, stream=0):
+        self._check(
+            self._lib.sdfgpu_render_dev(
+                self._h, C.byref(cam), width, height, C.byref(mp), d_hit, d_depth, d_normal, d_prim, stream
+            )
+        )
+
     def render_tiles_dev(self, cam, width, height, mp, tile_first, tile_stride, tile_count,
                          d_hit, d_depth, d_normal, d_prim, stream=0):
         self._check(

@@ -1,0 +1,51 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py).
+CPU: the oracle still reproduces them.  GPU: the kernels reproduce them through
+the C ABI without the oracle in the loop."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import bits
+from golden_util import GOLDEN, load
+
+IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
+
+
+def test_fixtures_exist():
+    assert len(GOLDEN) >= 6
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_oracle_reproduces_golden(path):
+    z, buf, cam, mp = load(path)
+    for mode in (O.MODE_FAUX, O.MODE_EXHAUSTIVE, O.MODE_TUNED):
+        d, i = O.nearest(buf, z["pts"], mode)
+        assert np.array_equal(bits(d), bits(z["dist"]))
+        if mode == O.MODE_FAUX and "duplicates_tie" in path:
+            # SURVEY C-6: the as-written un-margined prune may skip an exactly tying
+            # later duplicate; only the (build-defined) index can differ, never the distance
+            assert np.all(i <= z["prim"]) and (i != z["prim"]).mean() < 0.1
+        else:
+            assert np.array_equal(i, z["prim"])
+    kd, ki = O.knn(buf, z["pts"], 8)
+    assert np.array_equal(bits(kd), bits(z["knn_dist"])) and np.array_equal(ki, z["knn_prim"])
+    w, h = (int(v) for v in z["wh"])
+    img = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE)
+    assert np.array_equal(img["hit"], z["hit"]) and np.array_equal(img["prim"], z["rprim"])
+    assert np.array_equal(bits(img["depth"]), bits(z["depth"])) and np.array_equal(bits(img["normal"]), bits(z["normal"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bounds", [1, 2, 3], ids=["aabb", "obb", "none"])
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_gpu_reproduces_golden(gpu, path, bounds):
+    z, buf, cam, mp = load(path)
+    gpu.upload_tree(buf, bounds=bounds)
+    d, i = gpu.nearest(z["pts"])
+    assert np.array_equal(bits(d), bits(z["dist"])) and np.array_equal(i, z["prim"])
+    w, h = (int(v) for v in z["wh"])
+    img = gpu.render(cam, w, h, mp)
+    assert np.array_equal(img["hit"], z["hit"]) and np.array_equal(img["prim"], z["rprim"])
+    assert np.array_equal(bits(img["depth"]), bits(z["depth"])) and np.array_equal(bits(img["normal"]), bits(z["normal"]))

@@ -1,0 +1,170 @@
+"""Host scene builder (the C++ mirror of SdfBuilder / expanded / make_buffer)."""
+import numpy as np
+import pytest
+
+import sdf_amd as S
+from sdf_amd import _ffi
+
+
+def col_major(m16):
+    return np.asarray(m16, np.float64).reshape(4, 4).T   # -> [row, col]
+
+
+def tree_children(dt):
+    """children lists from `len`/`level`."""
+    n = len(dt)
+    kids = [[] for _ in range(n)]
+    for i in range(n):
+        k, end = i + 1, i + int(dt["len"][i])
+        while k <= end:
+            kids[i].append(k)
+            k += 1 + int(dt["len"][k])
+    return kids
+
+
+def test_single_sphere_buffer_matches_survey_E1_E3():
+    t = (3.0, -4.0, 5.5)
+    buf = (S.SdfBuilder.primitive(S.SdfSphere(2.0)).transform(S.Transform.from_translation(t))
+           .finalize().expanded().make_buffer())
+    assert buf.buffer_len == 1
+    b = buf.downtree_buffer[0]
+    assert (b["op_code"], b["is_primitive"], b["parent_is_union"], b["len"], b["level"]) == (0, 1, 0, 0, 1)
+    assert b["op_specific"]["floats"][0] == 2.0
+    ti = col_major(b["bounding_box"]["trans_inverse"])
+    assert np.array_equal(ti[:3, :3], np.eye(3)) and np.allclose(ti[:3, 3], [-3, 4, -5.5])
+    assert np.array_equal(ti[3], [0, 0, 0, 1])
+    m = col_major(b["bounding_box"]["matrix"])
+    assert np.allclose(m[:3, :3], 2 * np.eye(3)) and np.allclose(m[:3, 3], t)
+    assert np.allclose(b["bounding_box"]["scale"], [2, 2, 2, 0])
+    fi = col_major(b["bounding_box"]["full_inverse"])
+    assert np.allclose(fi @ m, np.eye(4), atol=1e-6)
+    u = buf.uptree_buffer[0]
+    assert (u["op_code"], u["level"]) == (0, 1)
+
+
+def test_transform_composition_order_E2():
+    # .transform(A).transform(B): trans_inverse = A^-1 B^-1, matrix = B A S   (obb.rs:226-243)
+    A = S.Transform.from_translation((1.0, 2.0, 3.0))
+    B = S.Transform.from_rotation(S.Quat.from_euler_xyz(0.3, 1.1, -0.7))
+    buf = S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(A).transform(B).finalize().expanded().make_buffer()
+    bb = buf.downtree_buffer[0]["bounding_box"]
+    Am, Bm = A.compute_matrix(), B.compute_matrix()
+    assert np.allclose(col_major(bb["trans_inverse"]), np.linalg.inv(Am) @ np.linalg.inv(Bm), atol=1e-5)
+    assert np.allclose(col_major(bb["matrix"]), Bm @ Am @ np.diag([1.5, 1.5, 1.5, 1]), atol=1e-5)
+    assert np.allclose(col_major(bb["full_inverse"]) @ col_major(bb["matrix"]), np.eye(4), atol=1e-5)
+
+
+def test_builder_slot_rules():
+    with pytest.raises(S.SdfError):
+        S.SdfBuilder.primitive(S.SdfUnion(0.0))                     # node.rs:377 assert
+    b = S.SdfBuilder.primitive(S.SdfSphere(1.0))
+    with pytest.raises(S.SdfError, match="primitive"):
+        b.with_(S.SdfBuilder.primitive(S.SdfSphere(1.0)))           # node.rs:171-172
+    used = S.SdfBuilder.primitive(S.SdfSphere(1.0))
+    used.finalize()
+    with pytest.raises(S.SdfError, match="consumed"):
+        used.finalize()
+
+
+def test_one_slot_union_vanishes():
+    # elements.rs:173: a union with one child expands to the child
+    buf = (S.SdfBuilder.primitive(S.SdfSphere(1.0)).transform(S.Transform.from_xyz(1, 0, 0))
+           .operation(S.SdfUnion(0.0)).finalize().expanded().make_buffer())
+    assert buf.buffer_len == 1 and buf.downtree_buffer[0]["is_primitive"] == 1
+
+
+def test_empty_union_is_empty_buffer():
+    node = S.random_scene(0, 1)
+    buf = node.expanded().make_buffer()
+    assert buf.buffer_len == 0
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 64, 1000])
+def test_make_buffer_invariants(n):
+    buf = S.random_scene_buffer(n, 0xABC0 + n)
+    dt, ut = buf.downtree_buffer, buf.uptree_buffer
+    assert buf.buffer_len == 2 * n - 1 and buf.n_prims == n        # binary tree over n leaves
+    assert dt["level"][0] == 1 and dt["len"][0] == buf.buffer_len - 1 and dt["parent_is_union"][0] == 0
+    kids = tree_children(dt)
+    post = []
+
+    def walk(i):
+        assert int(dt["is_primitive"][i]) == (1 if not kids[i] else 0)
+        if not dt["is_primitive"][i]:
+            assert len(kids[i]) == 2 and dt["op_code"][i] == _ffi.OP_UNION
+        for k in kids[i]:
+            assert dt["level"][k] == dt["level"][i] + 1 and dt["parent_is_union"][k] == 1
+            walk(k)
+        post.append(i)
+
+    walk(0)
+    assert len(post) == buf.buffer_len
+    # uptree = post-order of the same nodes (node.rs:124-129)
+    assert np.array_equal(ut["level"], dt["level"][post]) and np.array_equal(ut["op_code"], dt["op_code"][post])
+    # median split (obb.rs:212) -> balanced: depth = ceil(log2 n) + 1
+    assert dt["level"].max() == int(np.ceil(np.log2(n))) + 1
+    # other_box is the node's own box (node.rs:110-121, SURVEY C-2); root gets the zero box
+    assert np.array_equal(dt["other_box"]["matrix"][1:], dt["bounding_box"]["matrix"][1:])
+    assert np.all(dt["other_box"]["matrix"][0] == 0)
+    # internal nodes carry identity trans_inverse (SURVEY C-3 decision)
+    inner = dt[dt["is_primitive"] == 0]
+    assert np.all(inner["bounding_box"]["trans_inverse"] == np.eye(4, dtype=np.float32).reshape(-1))
+
+
+def test_every_primitive_appears_exactly_once_C1():
+    # the crate's expand re-uses slots 0/1/2 for unions with >= 3 children (SURVEY C-1); ours must not
+    n = 257
+    buf = S.random_scene_buffer(n, 99)
+    prims = buf.downtree_buffer[buf.downtree_buffer["is_primitive"] == 1]
+    t = prims["bounding_box"]["matrix"][:, 12:15]
+    assert len(np.unique(t, axis=0)) == n
+
+
+def test_boxes_contain_their_subtrees():
+    # geometric consistency (what makes pruning result-preserving): every leaf
+    # box corner lies inside every ancestor's box
+    buf = S.random_scene_buffer(200, 5)
+    dt = buf.downtree_buffer
+    kids = tree_children(dt)
+    corners = np.array([[sx, sy, sz, 1.0] for sx in (1, -1) for sy in (1, -1) for sz in (1, -1)])
+
+    def leaves(i):
+        return [i] if dt["is_primitive"][i] else [l for k in kids[i] for l in leaves(k)]
+
+    for i in range(len(dt)):
+        if dt["is_primitive"][i]:
+            continue
+        fi = col_major(dt["bounding_box"]["full_inverse"][i])
+        for l in leaves(i):
+            w = (col_major(dt["bounding_box"]["matrix"][l]) @ corners.T)
+            local = fi @ w
+            assert np.abs(local[:3]).max() <= 1.0 + 1e-6
+
+
+def test_mindist_maxdist_of_sphere_box_E3():
+    b = S.SdfBuilder.primitive(S.SdfSphere(2.0)).finalize().bbox
+    lib = _ffi.load_library()
+    p = np.array([5.0, 0, 0], np.float32)
+    assert abs(lib.sdfhost_bbox_distance_to(b.ctypes.data if hasattr(b, "ctypes") else np.array([b]).ctypes.data, _ffi.fptr(p)) - 3.0) < 1e-6
+    far = lib.sdfhost_bbox_max_distance(np.array([b]).ctypes.data, _ffi.fptr(p))
+    assert abs(far - np.linalg.norm([7.0, 2.0, 2.0])) < 1e-5
+
+
+def test_pca_trans_inverse_option_C3():
+    buf = S.random_scene(9, 3, opts={"pca_trans_inverse": True}).expanded().make_buffer()
+    inner = buf.downtree_buffer[buf.downtree_buffer["is_primitive"] == 0]
+    assert not np.all(inner["bounding_box"]["trans_inverse"] == np.eye(4, dtype=np.float32).reshape(-1))
+    for ti in inner["bounding_box"]["trans_inverse"]:
+        r = col_major(ti)[:3, :3]
+        assert np.allclose(r @ r.T, np.eye(3), atol=1e-5)
+
+
+def test_scene_is_deterministic_and_save_load_roundtrip(tmp_path):
+    a = S.random_scene_buffer(50, 1234)
+    b = S.random_scene_buffer(50, 1234)
+    assert a.downtree_buffer.tobytes() == b.downtree_buffer.tobytes()
+    assert a.uptree_buffer.tobytes() == b.uptree_buffer.tobytes()
+    p = str(tmp_path / "t.npz")
+    a.save(p)
+    c = S.SdfTreeBuffer.load(p)
+    assert c.downtree_buffer.tobytes() == a.downtree_buffer.tobytes() and c.buffer_len == a.buffer_len
