@@ -152,6 +152,12 @@ int sdfgpu_nearest(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n,
 int sdfgpu_nearest_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
                        float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
 
+/* Query batches of >= 2048 points are processed in Morton order (results are
+ * still written at the caller's index); 0 disables that.  Default: enabled.
+ * No reference counterpart.  The reordering scratch belongs to the context, so
+ * only one nearest/knn call per context may be in flight at a time. */
+int sdfgpu_set_reorder(sdfgpu_ctx* ctx, int enabled);
+
 /* k nearest primitives (extension of the k = 1 reference, README.md:7):
  * out_*[i*k + j], ascending by (distance, then larger index first), padded
  * with (+inf, SDF_NO_PRIM). */

@@ -133,6 +133,7 @@ GPU_SYMBOLS = {
     "sdfgpu_tree_info_get": (_i, [_vp, C.POINTER(TreeInfo)]),
     "sdfgpu_nearest": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sdfgpu_nearest_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "sdfgpu_set_reorder": (_i, [_vp, _i]),
     "sdfgpu_knn": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "sdfgpu_knn_dev": (_i, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),
     "sdfgpu_render": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _vp, _vp, _vp, _vp]),

@@ -30,6 +30,9 @@ struct sdfgpu_ctx {
     std::string err;
     // grow-only scratch for the host-pointer entry points
     DevBuf in, out_a, out_b, out_c, out_d, stats;
+    // Morton reordering of query batches (sort.hip)
+    DevBuf keys_a, keys_b, idx_a, idx_b, sort_tmp;
+    bool reorder = true;
 };
 
 namespace {
@@ -79,6 +82,31 @@ int check_march(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
     if (!cam || !mp) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null camera / march params");
     if (w == 0 || h == 0) return set_err(c, SDFGPU_ERR_INVALID_ARG, "empty image");
     if ((uint64_t)w * h > (1ull << 30)) return set_err(c, SDFGPU_ERR_TOO_LARGE, "image larger than 2^30 pixels");
+    return SDFGPU_OK;
+}
+
+// Morton permutation of a device point batch (nullptr when reordering is off
+// or not worth it).  Scratch is grow-only, so steady-state calls allocate nothing.
+constexpr size_t REORDER_MIN_POINTS = 2048;
+int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const uint32_t** order) {
+    *order = nullptr;
+    if (!c->reorder || n < REORDER_MIN_POINTS) return SDFGPU_OK;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        // twice the scene box: queries usually sit around the scene; outliers are clamped
+        float cen = 0.5f * (c->info.scene_lo[a] + c->info.scene_hi[a]);
+        float half = (c->info.scene_hi[a] - c->info.scene_lo[a]) + 1.0f;
+        lo[a] = cen - half;
+        hi[a] = cen + half;
+    }
+    int rc;
+    const size_t tmp = sort_temp_bytes((uint32_t)n);
+    if ((rc = reserve(c, c->keys_a, n * 4)) || (rc = reserve(c, c->keys_b, n * 4)) || (rc = reserve(c, c->idx_a, n * 4)) ||
+        (rc = reserve(c, c->idx_b, n * 4)) || (rc = reserve(c, c->sort_tmp, tmp)))
+        return rc;
+    HIP_TRY(c, launch_morton_order(d_pts, (uint32_t)n, lo, hi, (uint32_t*)c->keys_a.p, (uint32_t*)c->keys_b.p,
+                                   (uint32_t*)c->idx_a.p, (uint32_t*)c->idx_b.p, c->sort_tmp.p, tmp, s));
+    *order = (const uint32_t*)c->idx_b.p;
     return SDFGPU_OK;
 }
 
@@ -134,7 +162,8 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_tree(c);
-    for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats})
+    for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats, &c->keys_a, &c->keys_b, &c->idx_a,
+                      &c->idx_b, &c->sort_tmp})
         if (b->p) (void)hipFree(b->p);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -198,7 +227,9 @@ int sdfgpu_nearest_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, float* d_dis
     if (n == 0) return SDFGPU_OK;
     if (!d_pts || !d_dist) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null device pointer");
     if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
-    HIP_TRY(c, launch_nearest(c->tree, d_pts, nullptr, (uint32_t)n, d_dist, d_prim, nullptr, (hipStream_t)stream));
+    const uint32_t* order = nullptr;
+    if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order))) return rc;
+    HIP_TRY(c, launch_nearest(c->tree, d_pts, order, (uint32_t)n, d_dist, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
 }
 
@@ -232,18 +263,52 @@ int sdfgpu_nearest_stats_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, sdfgpu
     if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
     if ((rc = reserve(c, c->stats, sizeof(sdfgpu_stats))) || (rc = reserve(c, c->out_a, n * 4)) || (rc = reserve(c, c->out_b, n * 4))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, sizeof(sdfgpu_stats), c->stream));
-    HIP_TRY(c, launch_nearest(c->tree, d_pts, nullptr, (uint32_t)n, (float*)c->out_a.p, (uint32_t*)c->out_b.p,
+    const uint32_t* order = nullptr;
+    if ((rc = make_order(c, d_pts, n, c->stream, &order))) return rc;
+    HIP_TRY(c, launch_nearest(c->tree, d_pts, order, (uint32_t)n, (float*)c->out_a.p, (uint32_t*)c->out_b.p,
                               (sdfgpu_stats*)c->stats.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SDFGPU_OK;
 }
 
-int sdfgpu_knn_dev(sdfgpu_ctx* c, const float*, size_t, uint32_t, float*, uint32_t*, void*) {
-    return set_err(c, SDFGPU_ERR_INVALID_ARG, "kNN kernel not built yet");
+int sdfgpu_set_reorder(sdfgpu_ctx* c, int enabled) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    c->reorder = enabled != 0;
+    return SDFGPU_OK;
 }
-int sdfgpu_knn(sdfgpu_ctx* c, const float*, size_t, uint32_t, float*, uint32_t*) {
-    return set_err(c, SDFGPU_ERR_INVALID_ARG, "kNN kernel not built yet");
+
+int sdfgpu_knn_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, uint32_t k, float* d_dist, uint32_t* d_prim,
+                   void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (k == 0 || k > SDFGPU_MAX_K) return set_err(c, SDFGPU_ERR_TOO_LARGE, "k must be in 1..SDFGPU_MAX_K (16)");
+    if (n == 0) return SDFGPU_OK;
+    if (!d_pts || !d_dist || !d_prim) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null device pointer");
+    if (n > 0x7FFFFFFFull / k) return set_err(c, SDFGPU_ERR_TOO_LARGE, "n * k exceeds 2^31-1 in one call");
+    const uint32_t* order = nullptr;
+    if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order))) return rc;
+    HIP_TRY(c, launch_knn(c->tree, d_pts, order, (uint32_t)n, k, d_dist, d_prim, (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_knn(sdfgpu_ctx* c, const float* pts, size_t n, uint32_t k, float* out_dist, uint32_t* out_prim) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (k == 0 || k > SDFGPU_MAX_K) return set_err(c, SDFGPU_ERR_TOO_LARGE, "k must be in 1..SDFGPU_MAX_K (16)");
+    if (n == 0) return SDFGPU_OK;
+    if (!pts || !out_dist || !out_prim) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null pointer");
+    for (size_t i = 0; i < n; ++i)
+        if (pts[4 * i + 3] != 1.0f) return set_err(c, SDFGPU_ERR_POINT_W, "a query point has w != 1");
+    if ((rc = reserve(c, c->in, n * 16)) || (rc = reserve(c, c->out_a, n * k * 4)) || (rc = reserve(c, c->out_b, n * k * 4)))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->in.p, pts, n * 16, hipMemcpyHostToDevice, c->stream));
+    rc = sdfgpu_knn_dev(c, (const float*)c->in.p, n, k, (float*)c->out_a.p, (uint32_t*)c->out_b.p, c->stream);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_dist, c->out_a.p, n * k * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_prim, c->out_b.p, n * k * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
 }
 
 int sdfgpu_render_tiles_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,

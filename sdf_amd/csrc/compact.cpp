@@ -332,8 +332,20 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     info.rigid_leaves = rigid ? 1 : 0;
     info.device_bytes = out->leaves.size() * sizeof(GpuLeaf) + out->inner.size() * sizeof(GpuInner) +
                         out->inner_obb.size() * sizeof(GpuInnerObb);
-    if (mode == SDFGPU_BOUNDS_AABB)
-        for (int a = 0; a < 3; ++a) { info.scene_lo[a] = (float)root.lo[a]; info.scene_hi[a] = (float)root.hi[a]; }
+    // scene box (query reordering uses it in every mode; exact only for rigid leaves)
+    {
+        Box3 sb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!dt[i].is_primitive) continue;
+            Box3 lb{};
+            if (!leaf_aabb(dt[i], &lb)) continue;
+            for (int a = 0; a < 3; ++a) { sb.lo[a] = std::min(sb.lo[a], lb.lo[a]); sb.hi[a] = std::max(sb.hi[a], lb.hi[a]); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            info.scene_lo[a] = std::isfinite(sb.lo[a]) ? (float)sb.lo[a] : 0.f;
+            info.scene_hi[a] = std::isfinite(sb.hi[a]) ? (float)sb.hi[a] : 0.f;
+        }
+    }
     return SDFGPU_OK;
 }
 

@@ -258,6 +258,127 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     if constexpr (COUNT) flush_counters(wc, lane, 0, 0, st);
 }
 
+
+// ---------------------------------------------------------------- K2: kNN --
+// k nearest primitives (extension of the k = 1 reference, README.md:7: "based
+// off the existing branch-and-prune R-tree kNN algorithm").  Same walk as K1;
+// the prune radius is the k-th best so far.  The k best live in registers,
+// sorted ascending by (distance, larger index first) -- the order that
+// take_better induces -- and are padded with (+inf, SDF_NO_PRIM).
+template <int K>
+struct KBest {
+    float d[K];
+    uint32_t id[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { d[j] = __builtin_inff(); id[j] = SDF_NO_PRIM; }
+    }
+    __device__ __forceinline__ static bool before(float da, uint32_t ia, float db, uint32_t ib) {
+        return (da < db) || (da == db && ia > ib && ia != SDF_NO_PRIM) || (da == db && ib == SDF_NO_PRIM && ia != SDF_NO_PRIM);
+    }
+    __device__ __forceinline__ void insert(float nd, uint32_t nid) {
+        if (!before(nd, nid, d[K - 1], id[K - 1])) return;
+        d[K - 1] = nd;
+        id[K - 1] = nid;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            const bool sw = before(d[j], id[j], d[j - 1], id[j - 1]);
+            const float td = d[j]; const uint32_t ti = id[j];
+            d[j] = sw ? d[j - 1] : d[j];   id[j] = sw ? id[j - 1] : id[j];
+            d[j - 1] = sw ? td : d[j - 1]; id[j - 1] = sw ? ti : id[j - 1];
+        }
+    }
+};
+
+template <int MODE, int K>
+__global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __restrict__ pts,
+                                                  const uint32_t* __restrict__ order, uint32_t n, uint32_t k,
+                                                  float* __restrict__ out_dist, uint32_t* __restrict__ out_prim) {
+    extern __shared__ float smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float* __restrict__ stk = smem + wave * T.depth * 64u;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const bool alive = slot < n;
+    const uint32_t src = alive ? (order ? order[slot] : slot) : 0u;
+    float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (alive) p = pts[src];
+    const float px = p.x, py = p.y, pz = p.z;
+    KBest<K> kb;
+    kb.init();
+
+    uint32_t cur = T.root;
+    if (cur != REF_NONE) {
+        const float mg_k = (MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f;
+        const float mg = mg_k * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + T.margin_T);
+        uint32_t sp = 0;
+        int refs = 0;
+        for (;;) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            bool pop = false;
+            if (cur & REF_LEAF) {
+                const uint32_t id = cur & REF_INDEX;
+                kb.insert(leaf_eval(T.leaf + id, px, py, pz), id);
+                pop = true;
+            } else {
+                float k0, k1;
+                uint32_t r0, r1;
+                if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
+                    const GpuInnerObb* __restrict__ N = T.inner_obb + cur;
+                    k0 = obb_mindist(N->fi0, N->sc0, px, py, pz);
+                    k1 = obb_mindist(N->fi1, N->sc1, px, py, pz);
+                    r0 = N->ref0; r1 = N->ref1;
+                } else {
+                    const GpuInner* __restrict__ N = T.inner + cur;
+                    k0 = aabb_dist2(N->lo0, N->hi0, px, py, pz);
+                    k1 = aabb_dist2(N->lo1, N->hi1, px, py, pz);
+                    r0 = N->ref0; r1 = N->ref1;
+                }
+                const float thr = prune_threshold<MODE>(kb.d[K - 1], mg);
+                const bool w0 = alive && needed<MODE>(k0, thr);
+                const bool w1 = alive && needed<MODE>(k1, thr);
+                const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
+                if (b0 != 0ull && b1 != 0ull) {
+                    const unsigned long long n0 = __ballot(w0 && (!w1 || k0 <= k1));
+                    const unsigned long long n1 = __ballot(w1 && (!w0 || k1 < k0));
+                    const bool first0 = __popcll(n0) >= __popcll(n1);
+                    stk[sp * 64u + lane] = first0 ? k1 : k0;
+                    refs = (lane == sp) ? (int)(first0 ? r1 : r0) : refs;
+                    sp += 1;
+                    cur = first0 ? r0 : r1;
+                } else if (b0 != 0ull) {
+                    cur = r0;
+                } else if (b1 != 0ull) {
+                    cur = r1;
+                } else {
+                    pop = true;
+                }
+            }
+            if (pop) {
+                bool found = false;
+                while (sp != 0) {
+                    sp -= 1;
+                    const float kk = stk[sp * 64u + lane];
+                    const float thr = prune_threshold<MODE>(kb.d[K - 1], mg);
+                    if (__ballot(alive && needed<MODE>(kk, thr)) != 0ull) {
+                        cur = (uint32_t)__builtin_amdgcn_readlane(refs, sp);
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found) break;
+            }
+        }
+    }
+    if (alive) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if ((uint32_t)j < k) {
+                out_dist[(size_t)src * k + j] = kb.d[j];
+                out_prim[(size_t)src * k + j] = kb.id[j];
+            }
+    }
+}
+
 // ------------------------------------------------- K3 + K4: march, normal --
 // March loop (build-defined; restated by oracle_render):
 //   t = t_min; repeat max_steps times: p = o + d*t; (delta, id) = NN(p);
@@ -424,6 +545,28 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t*
                           uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     return st ? launch_nearest_t<true>(d, pts, order, n, out_dist, out_prim, st, s)
               : launch_nearest_t<false>(d, pts, order, n, out_dist, out_prim, nullptr, s);
+}
+
+
+template <int MODE>
+static hipError_t launch_knn_m(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, uint32_t k,
+                               float* out_dist, uint32_t* out_prim, hipStream_t s) {
+    TreeView v = make_view(d);
+    dim3 grid((n + 255u) / 256u), block(256);
+    size_t lds = (size_t)4 * d.stack_depth * 64 * sizeof(float);
+    const float4* p4 = (const float4*)pts;
+    if (k <= 2) knn_kernel<MODE, 2><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
+    else if (k <= 4) knn_kernel<MODE, 4><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
+    else if (k <= 8) knn_kernel<MODE, 8><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
+    else knn_kernel<MODE, 16><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, uint32_t k,
+                      float* out_dist, uint32_t* out_prim, hipStream_t s) {
+    if (n == 0 || k == 0) return hipSuccess;
+    return d.bounds == SDFGPU_BOUNDS_OBB ? launch_knn_m<SDFGPU_BOUNDS_OBB>(d, pts, order, n, k, out_dist, out_prim, s)
+                                         : launch_knn_m<SDFGPU_BOUNDS_AABB>(d, pts, order, n, k, out_dist, out_prim, s);
 }
 
 template <bool COUNT>

@@ -23,6 +23,16 @@ struct DeviceTree {
 hipError_t launch_nearest(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n,
                           float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s);
 
+// k nearest (k <= SDFGPU_MAX_K): out[i*k + j], ascending by (distance, larger index first).
+hipError_t launch_knn(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n, uint32_t k,
+                      float* out_dist, uint32_t* out_prim, hipStream_t s);
+
+// Morton order of a query batch inside [lo, hi): idx_out = permutation (sort.hip).
+size_t sort_temp_bytes(uint32_t n);
+hipError_t launch_morton_order(const float* pts_xyzw, uint32_t n, const float lo[3], const float hi[3],
+                               uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* idx_out, void* temp,
+                               size_t temp_bytes, hipStream_t s);
+
 hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
                          const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
                          bool row_major, uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st,

@@ -1,0 +1,59 @@
+// sort.hip -- spatial reordering of query batches.  The walk in kernels.hip is
+// wave-uniform: a wavefront visits the union of what its 64 lanes need, so 64
+// unrelated points would each pay for all the others.  Queries are therefore
+// processed in Morton order (30-bit code inside the scene box); results are
+// written back at the caller's original index, so the order is invisible.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace sdfgpu {
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ pts, uint32_t n, float lox, float loy,
+                                                     float loz, float sx, float sy, float sz,
+                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const float fx = __builtin_fminf(__builtin_fmaxf((p.x - lox) * sx, 0.f), 1023.f);
+    const float fy = __builtin_fminf(__builtin_fmaxf((p.y - loy) * sy, 0.f), 1023.f);
+    const float fz = __builtin_fminf(__builtin_fmaxf((p.z - loz) * sz, 0.f), 1023.f);
+    // NaN coordinates fall to cell 0 (fmax/fmin return the non-NaN operand)
+    keys[i] = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+    idx[i] = i;
+}
+
+size_t sort_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    uint32_t* k = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, (int)n, 0, 30, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t launch_morton_order(const float* pts, uint32_t n, const float lo[3], const float hi[3], uint32_t* keys_in,
+                               uint32_t* keys_out, uint32_t* idx_in, uint32_t* idx_out, void* temp, size_t temp_bytes,
+                               hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    float sc[3];
+    for (int a = 0; a < 3; ++a) {
+        float ext = hi[a] - lo[a];
+        sc[a] = ext > 0.f ? 1024.0f / ext : 0.f;
+    }
+    morton_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, s>>>((const float4*)pts, n, lo[0], lo[1], lo[2], sc[0], sc[1],
+                                                                sc[2], keys_in, idx_in);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, 30, s);
+}
+
+}  // namespace sdfgpu

@@ -104,6 +104,9 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_nearest_stats_dev(self._h, d_pts, n, C.byref(st)))
         return st.as_dict()
 
+    def set_reorder(self, enabled):
+        self._check(self._lib.sdfgpu_set_reorder(self._h, 1 if enabled else 0))
+
     def knn(self, pts_xyzw, k):
         p = np.ascontiguousarray(pts_xyzw, dtype=np.float32).reshape(-1, 4)
         n = p.shape[0]

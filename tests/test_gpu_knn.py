@@ -1,0 +1,71 @@
+"""GPU parity: sdfgpu_knn (K2) against the oracle's exhaustive top-k, and the
+Morton-reordered query path against the unordered one."""
+import numpy as np
+import pytest
+
+import sdf_amd as S
+from oracle import oracle as O
+from conftest import bits, make_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE])
+@pytest.mark.parametrize("n,k", [(1, 8), (3, 8), (5, 3), (64, 1), (200, 8), (200, 16), (1000, 8)])
+def test_knn_matches_oracle(gpu, n, k, bounds):
+    buf = S.random_scene_buffer(n, 0x4B00 + n)
+    pts = make_points(3000, S.default_extent(n), seed=n + k)
+    gpu.upload_tree(buf, bounds=bounds)
+    d, i = gpu.knn(pts, k)
+    d0, i0 = O.knn(buf, pts, k, threads=8)
+    assert np.array_equal(bits(d), bits(d0))
+    assert np.array_equal(i, i0)
+
+
+def test_knn_first_column_is_nearest(gpu):
+    buf = S.random_scene_buffer(300, 12)
+    pts = make_points(5000, S.default_extent(300), 13)
+    gpu.upload_tree(buf)
+    d, i = gpu.knn(pts, 8)
+    d1, i1 = gpu.nearest(pts)
+    assert np.array_equal(bits(d[:, 0]), bits(d1)) and np.array_equal(i[:, 0], i1)
+    assert np.all(np.diff(d, axis=1) >= 0)
+
+
+def test_knn_duplicates_order_and_padding(gpu):
+    t = S.Transform.from_translation((1.0, 2.0, 3.0))
+    b = (S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(t).operation(S.SdfUnion(0.0))
+         .with_(S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(t))
+         .with_(S.SdfBuilder.primitive(S.SdfBox((1, 2, 3))).transform(S.Transform.from_translation((9.0, 0, 0)))))
+    buf = b.finalize().expanded().make_buffer()
+    pts = make_points(512, 10.0, 3)
+    gpu.upload_tree(buf)
+    d, i = gpu.knn(pts, 8)
+    d0, i0 = O.knn(buf, pts, 8)
+    assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+    assert np.all(np.isposinf(d[:, 3:])) and np.all(i[:, 3:] == S.NO_PRIM)
+
+
+def test_k_out_of_range(gpu):
+    gpu.upload_tree(S.random_scene_buffer(4, 1))
+    for k in (0, 17):
+        with pytest.raises(S.SdfGpuError) as e:
+            gpu.knn(make_points(4, 1.0, 1), k)
+        assert e.value.status == S._ffi.ERR_TOO_LARGE
+
+
+def test_reordering_is_invisible(gpu):
+    buf = S.random_scene_buffer(500, 44)
+    pts = make_points(50000, S.default_extent(500), 45, scale=3.0)   # some points far outside the scene box
+    gpu.upload_tree(buf)
+    gpu.set_reorder(True)
+    d_on, i_on = gpu.nearest(pts)
+    k_on = gpu.knn(pts, 4)
+    gpu.set_reorder(False)
+    d_off, i_off = gpu.nearest(pts)
+    k_off = gpu.knn(pts, 4)
+    gpu.set_reorder(True)
+    assert np.array_equal(bits(d_on), bits(d_off)) and np.array_equal(i_on, i_off)
+    assert np.array_equal(bits(k_on[0]), bits(k_off[0])) and np.array_equal(k_on[1], k_off[1])
+    d0, i0 = O.nearest(buf, pts, O.MODE_TUNED, threads=8)
+    assert np.array_equal(bits(d_on), bits(d0)) and np.array_equal(i_on, i0)
