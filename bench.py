@@ -43,7 +43,12 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none"])
+    ap.add_argument("--skip-ext", type=float, default=0.0, help="SDFGPU_OPT_SKIP_EXTENSION (<0: half the mean primitive size)")
+    ap.add_argument("--compaction", action="store_true", help="multi-pass march with ray compaction (SDFGPU_OPT_COMPACTION=1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
+    ap.add_argument("--knn-points", type=int, default=10_000_000)
+    ap.add_argument("--knn-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget of the baseline leg")
     return ap.parse_args()
 
@@ -84,6 +89,64 @@ def cpu_baseline(buf, cam, mp, w, h, budget_s):
     return out
 
 
+def knn_leg(a, rank, world, local_rank, dev, dist):
+    """BASELINE config 5: k = 8 nearest primitives for 10 M points against the
+    100k-primitive tree; the point array is cut into contiguous slices, one per
+    rank, results stay sharded (no collective on the data path)."""
+    wl = W.CONFIGS[5]
+    buf = W.scene(wl)
+    gpu = S.SdfGpu(local_rank)
+    info = gpu.upload_tree(buf)
+    n_total = a.knn_points
+    lo, hi = P.query_slice(rank, world, n_total)
+    pts_all = W.query_points(wl, n_total)
+    pts = torch.from_numpy(pts_all[lo:hi]).to(dev)
+    n = hi - lo
+    k = wl.k
+    d_out = torch.empty(n * k, dtype=torch.float32, device=dev)
+    i_out = torch.empty(n * k, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        gpu.knn_dev(pts.data_ptr(), n, k, d_out.data_ptr(), i_out.data_ptr(), stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.knn_steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    out = {
+        "metric": "kNN queries/s (k=8)", "value": n_total * a.knn_steps / el, "unit": "queries/s",
+        "ms_per_step": el / a.knn_steps * 1e3, "steps": a.knn_steps,
+        "config": {"workload": wl.name, "n_points": n_total, "k": k, "n_prims": wl.n_prims, "seed": hex(wl.seed),
+                   "tree_levels": int(info.max_level), "tree_bytes_hbm": int(info.device_bytes),
+                   "points": "uniform in 1.2x the scene cube, unsorted (Morton-reordered inside the call)",
+                   "partition": "contiguous query slices, results sharded"},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu:
+        from oracle import oracle as O
+        threads = max(1, min(O.hardware_threads(), len(os.sched_getaffinity(0))))
+        m = 20000
+        t0 = time.perf_counter()
+        O.nearest(buf, pts_all[:m], O.MODE_TUNED, threads=threads)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline_nearest"] = {"value": m / tc, "unit": "queries/s (k=1, tuned port)", "cores": threads,
+                                       "kind": "port", "sample": f"{m} of the same points, {tc:.2f} s"}
+    gpu.close()
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +173,8 @@ def main():
     bounds = {"auto": S.BOUNDS_AUTO, "aabb": S.BOUNDS_AABB, "obb": S.BOUNDS_OBB, "none": S.BOUNDS_NONE}[a.bounds]
     gpu = S.SdfGpu(local_rank)
     info = gpu.upload_tree(buf, bounds=bounds)
+    gpu.set_skip_extension(a.skip_ext)
+    gpu.set_compaction(a.compaction)
 
     npix = w * h
     tiles = P.n_tiles(w, h)
@@ -226,13 +291,21 @@ def main():
             }
             line["work"] = {
                 "steps_per_ray": st["steps"] / max(1, st["rays"]),
-                "inner_visits_per_query": st["inner_visits"] / max(1, st["queries"]),
-                "leaf_evals_per_query": (st["sphere_evals"] + st["box_evals"]) / max(1, st["queries"]),
+                "walks_per_ray": st["queries"] / max(1, st["rays"]),
+                "wave_steps": st["wave_steps"], "wave_walks": st["wave_walks"],
+                "inner_visits_per_walk": st["inner_visits"] / max(1, st["queries"]),
+                "leaf_evals_per_step": (st["sphere_evals"] + st["box_evals"]) / max(1, st["steps"]),
                 "wave_inner_visits": st["wave_inner"], "wave_leaf_visits": st["wave_leaf"],
                 "queries": st["queries"],
             }
             if not a.no_cpu:
                 line["cpu_baseline"] = cpu_baseline(buf, cam, mp, w, h, a.cpu_seconds)
+    knn = None
+    if not a.no_knn:
+        knn = knn_leg(a, rank, world, local_rank, dev, dist)
+    if rank == 0:
+        if knn is not None:
+            line["knn"] = knn
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -103,7 +103,7 @@ typedef struct sdfgpu_march_params {
 
 /* Per-launch work counters (instrumented variant of the same kernels). */
 typedef struct sdfgpu_stats {
-    uint64_t queries;        /* NN queries issued (one per lane per march step / per point) */
+    uint64_t queries;        /* tree walks driven, summed over lanes (render: steps not proven by kept bounds) */
     uint64_t inner_visits;   /* internal-node visits, summed over lanes */
     uint64_t sphere_evals;   /* primitive evaluations, summed over lanes */
     uint64_t box_evals;
@@ -111,6 +111,8 @@ typedef struct sdfgpu_stats {
     uint64_t wave_leaf;
     uint64_t steps;          /* march steps summed over rays */
     uint64_t rays;
+    uint64_t wave_steps;     /* march steps per wavefront */
+    uint64_t wave_walks;     /* ... of which needed a tree walk (the rest were proven by kept bounds) */
 } sdfgpu_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -152,11 +154,27 @@ int sdfgpu_nearest(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n,
 int sdfgpu_nearest_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
                        float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
 
-/* Query batches of >= 2048 points are processed in Morton order (results are
- * still written at the caller's index); 0 disables that.  Default: enabled.
- * No reference counterpart.  The reordering scratch belongs to the context, so
- * only one nearest/knn call per context may be in flight at a time. */
-int sdfgpu_set_reorder(sdfgpu_ctx* ctx, int enabled);
+/* Tuning knobs.  None of them can change a result, only the time it takes.
+ * No reference counterpart. */
+typedef enum sdfgpu_option {
+    /* 1 (default): nearest/knn batches of >= 2048 points are processed in Morton
+     * order (results are still written at the caller's index); 0: as given.  The
+     * reordering scratch belongs to the context, so only one nearest/knn call
+     * per context may be in flight at a time. */
+    SDFGPU_OPT_REORDER = 0,
+    /* render: how far (scene units) the tree walk looks beyond the nearest
+     * distance so that following march steps can be proven without a walk.
+     * 0 (default): no widening (steps are still proven when the bounds a walk
+     * leaves behind happen to allow it); < 0: half the mean primitive size, which
+     * pays off in dense scenes with long grazing rays. */
+    SDFGPU_OPT_SKIP_EXTENSION = 1,
+    /* render: 1 cuts the march into passes and re-packs the rays still
+     * marching, 64 to a wavefront, between them; 0 (default): one pass.  (On the
+     * 10k-primitive benchmark scene the late, sparse passes are latency bound
+     * and the single pass is faster; see DESIGN.md.) */
+    SDFGPU_OPT_COMPACTION = 2
+} sdfgpu_option;
+int sdfgpu_set_option(sdfgpu_ctx* ctx, int option, double value);
 
 /* k nearest primitives (extension of the k = 1 reference, README.md:7):
  * out_*[i*k + j], ascending by (distance, then larger index first), padded

@@ -55,6 +55,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_HIP, ERR_NO_TREE, ERR_LAYOUT, ERR_BAD_TREE = -1, -2, -3, -4, -5
 ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE = -6, -7, -8, -9, -10
 MAX_K = 16
+OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION = 0, 1, 2
 
 
 class TreeInfo(C.Structure):
@@ -103,6 +104,8 @@ class Stats(C.Structure):
         ("wave_leaf", C.c_uint64),
         ("steps", C.c_uint64),
         ("rays", C.c_uint64),
+        ("wave_steps", C.c_uint64),
+        ("wave_walks", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -133,7 +136,7 @@ GPU_SYMBOLS = {
     "sdfgpu_tree_info_get": (_i, [_vp, C.POINTER(TreeInfo)]),
     "sdfgpu_nearest": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sdfgpu_nearest_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
-    "sdfgpu_set_reorder": (_i, [_vp, _i]),
+    "sdfgpu_set_option": (_i, [_vp, _i, C.c_double]),
     "sdfgpu_knn": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "sdfgpu_knn_dev": (_i, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),
     "sdfgpu_render": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _vp, _vp, _vp, _vp]),

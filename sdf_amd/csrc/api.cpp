@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,7 +33,13 @@ struct sdfgpu_ctx {
     DevBuf in, out_a, out_b, out_c, out_d, stats;
     // Morton reordering of query batches (sort.hip)
     DevBuf keys_a, keys_b, idx_a, idx_b, sort_tmp;
+    // multi-pass march (ray compaction)
+    DevBuf march;
+    bool compaction = false;
+    std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
     bool reorder = true;
+    float skip_ext_opt = 0.f;    // SDFGPU_OPT_SKIP_EXTENSION as set (< 0: half the mean primitive size)
+    float mean_extent = 0.f;
 };
 
 namespace {
@@ -110,6 +117,49 @@ int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const
     return SDFGPU_OK;
 }
 
+
+// Pass boundaries of the multi-pass march for a given step budget, and the
+// scratch it needs.  Default schedule: survivors thin out quickly at first and
+// slowly later (DESIGN.md "ray compaction"); SDFGPU_PASS_STEPS="12,20,..."
+// overrides it for tuning.
+std::vector<uint32_t> default_pass_steps() {
+    std::vector<uint32_t> v;
+    if (const char* e = std::getenv("SDFGPU_PASS_STEPS")) {
+        const char* p = e;
+        while (*p) {
+            char* end = nullptr;
+            unsigned long x = std::strtoul(p, &end, 10);
+            if (end == p) break;
+            if (x > 0) v.push_back((uint32_t)x);
+            p = (*end == ',') ? end + 1 : end;
+        }
+        return v;
+    }
+    return {12, 20, 28, 40, 56, 80};
+}
+
+int march_setup(sdfgpu_ctx* c, uint32_t tile_count, uint32_t max_steps, RenderScratch* rs, std::vector<uint32_t>* bounds) {
+    bounds->clear();
+    bounds->push_back(0);
+    if (c->compaction)
+        for (uint32_t b : c->pass_steps)
+            if (b > bounds->back() && b < max_steps) bounds->push_back(b);
+    bounds->push_back(max_steps > 0 ? max_steps : 0);
+    if (bounds->size() == 2 && (*bounds)[1] == 0) (*bounds)[1] = 0;   // zero steps: one empty pass
+    size_t sb = 0, cb = 0;
+    const size_t total = render_scratch_bytes(tile_count, &sb, &cb);
+    int rc = reserve(c, c->march, total);
+    if (rc) return rc;
+    char* base = (char*)c->march.p;
+    rs->state[0] = base;
+    rs->state[1] = base + sb;
+    rs->counts = (uint32_t*)(base + 2 * sb);
+    rs->offsets = (uint32_t*)(base + 2 * sb + cb);
+    rs->hdr[0] = (uint32_t*)(base + 2 * sb + 2 * cb);
+    rs->hdr[1] = rs->hdr[0] + 4;
+    return SDFGPU_OK;
+}
+
 template <class T>
 int upload_vec(sdfgpu_ctx* c, const std::vector<T>& v, T** dst) {
     *dst = nullptr;
@@ -149,6 +199,7 @@ int sdfgpu_create(int device_id, sdfgpu_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return SDFGPU_ERR_HIP;
     sdfgpu_ctx* c = new sdfgpu_ctx();
     c->device = device_id;
+    c->pass_steps = default_pass_steps();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SDFGPU_ERR_HIP;
@@ -163,7 +214,7 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     free_tree(c);
     for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats, &c->keys_a, &c->keys_b, &c->idx_a,
-                      &c->idx_b, &c->sort_tmp})
+                      &c->idx_b, &c->sort_tmp, &c->march})
         if (b->p) (void)hipFree(b->p);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -208,6 +259,8 @@ int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOper
     c->tree.stack_depth = t.stack_depth;
     c->tree.bounds = t.info.bounds;
     c->tree.margin_T = t.margin_T;
+    c->mean_extent = t.mean_extent;
+    c->tree.skip_ext = c->skip_ext_opt < 0.f ? 0.5f * t.mean_extent : c->skip_ext_opt;
     c->info = t.info;
     c->has_tree = true;
     c->err.clear();
@@ -272,10 +325,22 @@ int sdfgpu_nearest_stats_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, sdfgpu
     return SDFGPU_OK;
 }
 
-int sdfgpu_set_reorder(sdfgpu_ctx* c, int enabled) {
+int sdfgpu_set_option(sdfgpu_ctx* c, int option, double value) {
     if (!c) return SDFGPU_ERR_INVALID_ARG;
-    c->reorder = enabled != 0;
-    return SDFGPU_OK;
+    switch (option) {
+        case SDFGPU_OPT_REORDER:
+            c->reorder = value != 0.0;
+            return SDFGPU_OK;
+        case SDFGPU_OPT_SKIP_EXTENSION:
+            if (!(value == value)) return set_err(c, SDFGPU_ERR_INVALID_ARG, "skip extension is NaN");
+            c->skip_ext_opt = (float)value;
+            c->tree.skip_ext = value < 0.0 ? 0.5f * c->mean_extent : (float)value;
+            return SDFGPU_OK;
+        case SDFGPU_OPT_COMPACTION:
+            c->compaction = value != 0.0;
+            return SDFGPU_OK;
+    }
+    return set_err(c, SDFGPU_ERR_INVALID_ARG, "unknown option");
 }
 
 int sdfgpu_knn_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, uint32_t k, float* d_dist, uint32_t* d_prim,
@@ -323,8 +388,11 @@ int sdfgpu_render_tiles_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w,
     const uint64_t tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
     if (tile_stride == 0 || (uint64_t)tile_first + (uint64_t)(tile_count - 1) * tile_stride >= tiles)
         return set_err(c, SDFGPU_ERR_INVALID_ARG, "tile range outside the frame");
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, tile_first, tile_stride, tile_count, false, d_hit, d_depth,
-                             d_normal, d_prim, nullptr, (hipStream_t)stream));
+    RenderScratch rs;
+    std::vector<uint32_t> pb;
+    if ((rc = march_setup(c, tile_count, mp->max_steps, &rs, &pb))) return rc;
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, tile_first, tile_stride, tile_count, false, rs, pb.data(),
+                             (uint32_t)pb.size(), d_hit, d_depth, d_normal, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
 }
 
@@ -335,8 +403,11 @@ int sdfgpu_render_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint3
     if ((rc = check_march(c, cam, w, h, mp))) return rc;
     if (!d_hit) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null hit buffer");
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, d_hit, d_depth, d_normal, d_prim, nullptr,
-                             (hipStream_t)stream));
+    RenderScratch rs;
+    std::vector<uint32_t> pb;
+    if ((rc = march_setup(c, tiles, mp->max_steps, &rs, &pb))) return rc;
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(), d_hit,
+                             d_depth, d_normal, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
 }
 
@@ -369,8 +440,12 @@ int sdfgpu_render(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t 
         (rc = reserve(c, c->out_d, np * 4)))
         return rc;
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, (uint8_t*)c->out_a.p, (float*)c->out_b.p,
-                             (float*)c->out_c.p, (uint32_t*)c->out_d.p, nullptr, c->stream));
+    RenderScratch rs;
+    std::vector<uint32_t> pb;
+    if ((rc = march_setup(c, tiles, mp->max_steps, &rs, &pb))) return rc;
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(),
+                             (uint8_t*)c->out_a.p, (float*)c->out_b.p, (float*)c->out_c.p, (uint32_t*)c->out_d.p, nullptr,
+                             c->stream));
     HIP_TRY(c, hipMemcpyAsync(hit, c->out_a.p, np, hipMemcpyDeviceToHost, c->stream));
     if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->out_b.p, np * 4, hipMemcpyDeviceToHost, c->stream));
     if (normal) HIP_TRY(c, hipMemcpyAsync(normal, c->out_c.p, np * 12, hipMemcpyDeviceToHost, c->stream));
@@ -389,8 +464,11 @@ int sdfgpu_render_stats(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uin
     if ((rc = reserve(c, c->out_a, np)) || (rc = reserve(c, c->stats, sizeof(sdfgpu_stats)))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, sizeof(sdfgpu_stats), c->stream));
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, (uint8_t*)c->out_a.p, nullptr, nullptr,
-                             nullptr, (sdfgpu_stats*)c->stats.p, c->stream));
+    RenderScratch rs;
+    std::vector<uint32_t> pb;
+    if ((rc = march_setup(c, tiles, mp->max_steps, &rs, &pb))) return rc;
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(),
+                             (uint8_t*)c->out_a.p, nullptr, nullptr, nullptr, (sdfgpu_stats*)c->stats.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SDFGPU_OK;

@@ -300,6 +300,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
 
     // ---- leaves, in primitive-id order ----
     out->leaves.resize(n_prims);
+    double extent_sum = 0.0;
     for (uint32_t i = 0; i < n; ++i) {
         if (!dt[i].is_primitive) continue;
         GpuLeaf& L = out->leaves[c.prim_id[i]];
@@ -314,7 +315,9 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         } else {
             for (int a = 0; a < 3; ++a) L.param[a] = dt[i].op_specific.vec4s[0].v[a];
         }
+        extent_sum += std::max({std::fabs((double)L.param[0]), std::fabs((double)L.param[1]), std::fabs((double)L.param[2])});
     }
+    out->mean_extent = n_prims ? (float)(extent_sum / n_prims) : 0.f;
     if (mode == SDFGPU_BOUNDS_OBB) out->inner_obb.reserve(n_inner);
     else out->inner.reserve(n_inner);
     Box3 root{};

@@ -57,11 +57,17 @@ __device__ __forceinline__ float leaf_eval(const GpuLeaf* __restrict__ L, float 
 // tree (faux_shader.rs:27-29,87): smaller distance, then the
 // LATER primitive.  Order-independent, so any visiting order gives the same
 // answer as the reference's pre-order walk.
+__device__ __forceinline__ bool is_better(float d, uint32_t id, float best, uint32_t bid) {
+    // bitwise on purpose: no short-circuit branches in the walk's inner loop
+    return (d < best) | ((d == best) & ((id > bid) | (bid == SDF_NO_PRIM)));
+}
 __device__ __forceinline__ void take_better(float d, uint32_t id, float& best, uint32_t& bid) {
-    bool b = (d < best) || (d == best && (id > bid || bid == SDF_NO_PRIM));
+    const bool b = is_better(d, id, best, bid);
     best = b ? d : best;
     bid = b ? id : bid;
 }
+// min without the canonicalising v_max the IEEE fminf needs (operands are never NaN here)
+__device__ __forceinline__ float min_nn(float a, float b) { return a < b ? a : b; }
 
 // --------------------------------------------------------------- bounds ---
 
@@ -97,10 +103,18 @@ struct TreeView {
     uint32_t root;
     uint32_t depth;     // LDS stack levels per wave
     float margin_T;
+    float skip_ext;     // widening of the search radius that pays for skipped walks (render)
 };
 
+// Absolute slack covering the rounding of a leaf value at point p (DESIGN.md "pruning").
+template <int MODE>
+__device__ __forceinline__ float prune_margin(const TreeView& T, float px, float py, float pz) {
+    const float mg_k = (MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f;
+    return mg_k * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + T.margin_T);
+}
+
 struct WaveCounters {
-    uint32_t wave_inner = 0, wave_leaf = 0;
+    uint32_t wave_inner = 0, wave_leaf = 0, wave_steps = 0, wave_walks = 0;
     uint32_t lane_inner = 0, lane_sphere = 0, lane_box = 0, lane_queries = 0;
 };
 
@@ -109,11 +123,11 @@ struct WaveCounters {
 // OBB mode compares MINDIST directly: pruned iff m > 0 && m > best + mg
 // (the reference's test, faux_shader.rs:119-120, plus the margin).
 template <int MODE>
-__device__ __forceinline__ float prune_threshold(float best, float mg) {
+__device__ __forceinline__ float prune_threshold(float best, float mg, float ext = 0.f) {
     if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
-        return best + mg;
+        return (best + mg) + ext;
     } else {
-        float bp = __builtin_fmaxf(best + mg, 0.f);
+        float bp = __builtin_fmaxf(best + mg, 0.f) + ext;
         return bp * bp * 1.0006f;
     }
 }
@@ -123,33 +137,66 @@ __device__ __forceinline__ bool needed(float key, float thr) {
     else return key <= thr;
 }
 
-// Wave-uniform branch-and-prune walk.  On return (best, bid) is the minimum
-// over every primitive of the tree under take_better's order, for each lane
-// with alive == true.  `stk` = this wave's LDS stack, [depth][64] floats.
-template <int MODE, bool COUNT>
-__device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, bool alive, float& best,
-                                            uint32_t& bid, float* __restrict__ stk, uint32_t lane, WaveCounters& wc) {
+// ---- accumulators: what a walk does with a primitive value / a skipped box ----
+// radius(): the distance beyond which nothing can matter any more (prune radius).
+
+// K1: the single best under take_better's order.
+struct AccNearest {
+    float best;
+    uint32_t bid;
+    __device__ __forceinline__ float radius() const { return best; }
+    __device__ __forceinline__ void offer(float d, uint32_t id) { take_better(d, id, best, bid); }
+    __device__ __forceinline__ void skipped(float) {}
+};
+
+// Render: the single best, plus lower bounds on everything that was NOT the
+// winner, which let later march steps prove "the same primitive is still the
+// nearest" without walking (valid for every lane, driving or not).
+struct AccTracked {
+    float best;
+    uint32_t bid;
+    float second;   // min computed distance over evaluated primitives other than the winner
+    float lb_key;   // min bound key (AABB: squared distance) over subtrees the walk skipped
+    __device__ __forceinline__ float radius() const { return best; }
+    __device__ __forceinline__ void offer(float d, uint32_t id) {
+        const bool rival = id != bid;   // the seed primitive is met again during the walk: not a rival
+        const bool b = rival & is_better(d, id, best, bid);
+        const float loser = b ? best : d;
+        second = (rival & (loser < second)) ? loser : second;
+        best = b ? d : best;
+        bid = b ? id : bid;
+    }
+    __device__ __forceinline__ void skipped(float key) { lb_key = min_nn(lb_key, key); }
+};
+
+// Wave-uniform branch-and-prune walk.  On return the accumulator holds the
+// result over every primitive of the tree for each lane whose bit is set in
+// `drive` (other lanes ride along: they see every value the wave evaluates).
+// `stk` = this wave's LDS stack, [depth][64] floats.  All decisions are made
+// on 64-bit lane masks in SGPRs; `ext` widens the search radius (render).
+template <int MODE, bool COUNT, class Acc>
+__device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, unsigned long long drive,
+                                            float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
+                                            WaveCounters& wc) {
     uint32_t cur = T.root;
     if (cur == REF_NONE) return;
-    const float mg_k = (MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f;
-    const float mg = mg_k * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + T.margin_T);
+    const float mg = prune_margin<MODE>(T, px, py, pz);
+    const bool mine = (drive >> lane) & 1ull;
     uint32_t sp = 0;
     int refs = 0;  // lane k holds the reference of stack entry k
-    if constexpr (COUNT) wc.lane_queries += alive ? 1u : 0u;
+    if constexpr (COUNT) wc.lane_queries += mine ? 1u : 0u;
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
-        bool pop = false;
+        bool descend = false;
         if (cur & REF_LEAF) {
             const uint32_t id = cur & REF_INDEX;
             const GpuLeaf* __restrict__ L = T.leaf + id;
-            float d = leaf_eval(L, px, py, pz);
-            take_better(d, id, best, bid);
+            acc.offer(leaf_eval(L, px, py, pz), id);
             if constexpr (COUNT) {
                 wc.wave_leaf += 1;
-                if (L->kind == SDF_PRIM_SPHERE) wc.lane_sphere += alive ? 1u : 0u;
-                else wc.lane_box += alive ? 1u : 0u;
+                if (L->kind == SDF_PRIM_SPHERE) wc.lane_sphere += mine ? 1u : 0u;
+                else wc.lane_box += mine ? 1u : 0u;
             }
-            pop = true;
         } else {
             float k0, k1;
             uint32_t r0, r1;
@@ -168,42 +215,41 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
             }
             if constexpr (COUNT) {
                 wc.wave_inner += 1;
-                wc.lane_inner += alive ? 1u : 0u;
+                wc.lane_inner += mine ? 1u : 0u;
             }
-            const float thr = prune_threshold<MODE>(best, mg);
-            const bool w0 = alive && needed<MODE>(k0, thr);
-            const bool w1 = alive && needed<MODE>(k1, thr);
-            const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
-            if (b0 != 0ull && b1 != 0ull) {
+            const float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(needed<MODE>(k0, thr)) & drive;
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(needed<MODE>(k1, thr)) & drive;
+            if (m0 != 0ull && m1 != 0ull) {
                 // both needed by someone: majority vote on which is nearer
-                const unsigned long long n0 = __ballot(w0 && (!w1 || k0 <= k1));
-                const unsigned long long n1 = __ballot(w1 && (!w0 || k1 < k0));
-                const bool first0 = __popcll(n0) >= __popcll(n1);
-                const uint32_t far = first0 ? r1 : r0;
-                const float kfar = first0 ? k1 : k0;
-                stk[sp * 64u + lane] = kfar;
-                refs = (lane == sp) ? (int)far : refs;   // v_writelane has no builtin here
+                const unsigned long long c = __builtin_amdgcn_ballot_w64(k0 <= k1);
+                const uint32_t n0 = (uint32_t)__builtin_popcountll(m0 & (c | ~m1));
+                const uint32_t n1 = (uint32_t)__builtin_popcountll(m1 & (~c | ~m0));
+                const bool first0 = n0 >= n1;
+                stk[sp * 64u + lane] = first0 ? k1 : k0;
+                refs = (lane == sp) ? (int)(first0 ? r1 : r0) : refs;   // v_writelane has no builtin here
                 sp += 1;
                 cur = first0 ? r0 : r1;
-            } else if (b0 != 0ull) {
-                cur = r0;
-            } else if (b1 != 0ull) {
-                cur = r1;
+                descend = true;
             } else {
-                pop = true;
+                if (m0 == 0ull) acc.skipped(k0);
+                if (m1 == 0ull) acc.skipped(k1);
+                cur = (m0 != 0ull) ? r0 : r1;
+                descend = (m0 | m1) != 0ull;
             }
         }
-        if (pop) {
+        if (!descend) {
             bool found = false;
             while (sp != 0) {
                 sp -= 1;
                 const float k = stk[sp * 64u + lane];
-                const float thr = prune_threshold<MODE>(best, mg);
-                if (__ballot(alive && needed<MODE>(k, thr)) != 0ull) {
+                const float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+                if ((__builtin_amdgcn_ballot_w64(needed<MODE>(k, thr)) & drive) != 0ull) {
                     cur = (uint32_t)__builtin_amdgcn_readlane(refs, sp);
                     found = true;
                     break;
                 }
+                acc.skipped(k);
             }
             if (!found) return;
         }
@@ -226,6 +272,8 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
         atomicAdd((unsigned long long*)&st->rays, (unsigned long long)v[5]);
         atomicAdd((unsigned long long*)&st->wave_inner, (unsigned long long)wc.wave_inner);
         atomicAdd((unsigned long long*)&st->wave_leaf, (unsigned long long)wc.wave_leaf);
+        atomicAdd((unsigned long long*)&st->wave_steps, (unsigned long long)wc.wave_steps);
+        atomicAdd((unsigned long long*)&st->wave_walks, (unsigned long long)wc.wave_walks);
     }
 }
 
@@ -250,7 +298,10 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     float best = __builtin_inff();
     uint32_t bid = SDF_NO_PRIM;
     WaveCounters wc;
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, alive, best, bid, stk, lane, wc);
+    AccNearest acc{best, bid};
+    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
+    best = acc.best;
+    bid = acc.bid;
     if (alive) {
         out_dist[src] = best;
         if (out_prim) out_prim[src] = bid;
@@ -266,7 +317,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
 // sorted ascending by (distance, larger index first) -- the order that
 // take_better induces -- and are padded with (+inf, SDF_NO_PRIM).
 template <int K>
-struct KBest {
+struct AccK {
     float d[K];
     uint32_t id[K];
     __device__ __forceinline__ void init() {
@@ -274,9 +325,11 @@ struct KBest {
         for (int j = 0; j < K; ++j) { d[j] = __builtin_inff(); id[j] = SDF_NO_PRIM; }
     }
     __device__ __forceinline__ static bool before(float da, uint32_t ia, float db, uint32_t ib) {
-        return (da < db) || (da == db && ia > ib && ia != SDF_NO_PRIM) || (da == db && ib == SDF_NO_PRIM && ia != SDF_NO_PRIM);
+        return (da < db) || (da == db && ia != SDF_NO_PRIM && (ia > ib || ib == SDF_NO_PRIM));
     }
-    __device__ __forceinline__ void insert(float nd, uint32_t nid) {
+    __device__ __forceinline__ float radius() const { return d[K - 1]; }
+    __device__ __forceinline__ void skipped(float) {}
+    __device__ __forceinline__ void offer(float nd, uint32_t nid) {
         if (!before(nd, nid, d[K - 1], id[K - 1])) return;
         d[K - 1] = nd;
         id[K - 1] = nid;
@@ -302,79 +355,16 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     const uint32_t src = alive ? (order ? order[slot] : slot) : 0u;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[src];
-    const float px = p.x, py = p.y, pz = p.z;
-    KBest<K> kb;
-    kb.init();
-
-    uint32_t cur = T.root;
-    if (cur != REF_NONE) {
-        const float mg_k = (MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f;
-        const float mg = mg_k * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + T.margin_T);
-        uint32_t sp = 0;
-        int refs = 0;
-        for (;;) {
-            cur = __builtin_amdgcn_readfirstlane(cur);
-            bool pop = false;
-            if (cur & REF_LEAF) {
-                const uint32_t id = cur & REF_INDEX;
-                kb.insert(leaf_eval(T.leaf + id, px, py, pz), id);
-                pop = true;
-            } else {
-                float k0, k1;
-                uint32_t r0, r1;
-                if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
-                    const GpuInnerObb* __restrict__ N = T.inner_obb + cur;
-                    k0 = obb_mindist(N->fi0, N->sc0, px, py, pz);
-                    k1 = obb_mindist(N->fi1, N->sc1, px, py, pz);
-                    r0 = N->ref0; r1 = N->ref1;
-                } else {
-                    const GpuInner* __restrict__ N = T.inner + cur;
-                    k0 = aabb_dist2(N->lo0, N->hi0, px, py, pz);
-                    k1 = aabb_dist2(N->lo1, N->hi1, px, py, pz);
-                    r0 = N->ref0; r1 = N->ref1;
-                }
-                const float thr = prune_threshold<MODE>(kb.d[K - 1], mg);
-                const bool w0 = alive && needed<MODE>(k0, thr);
-                const bool w1 = alive && needed<MODE>(k1, thr);
-                const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
-                if (b0 != 0ull && b1 != 0ull) {
-                    const unsigned long long n0 = __ballot(w0 && (!w1 || k0 <= k1));
-                    const unsigned long long n1 = __ballot(w1 && (!w0 || k1 < k0));
-                    const bool first0 = __popcll(n0) >= __popcll(n1);
-                    stk[sp * 64u + lane] = first0 ? k1 : k0;
-                    refs = (lane == sp) ? (int)(first0 ? r1 : r0) : refs;
-                    sp += 1;
-                    cur = first0 ? r0 : r1;
-                } else if (b0 != 0ull) {
-                    cur = r0;
-                } else if (b1 != 0ull) {
-                    cur = r1;
-                } else {
-                    pop = true;
-                }
-            }
-            if (pop) {
-                bool found = false;
-                while (sp != 0) {
-                    sp -= 1;
-                    const float kk = stk[sp * 64u + lane];
-                    const float thr = prune_threshold<MODE>(kb.d[K - 1], mg);
-                    if (__ballot(alive && needed<MODE>(kk, thr)) != 0ull) {
-                        cur = (uint32_t)__builtin_amdgcn_readlane(refs, sp);
-                        found = true;
-                        break;
-                    }
-                }
-                if (!found) break;
-            }
-        }
-    }
+    AccK<K> acc;
+    acc.init();
+    WaveCounters wc;
+    nn_traverse<MODE, false>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
     if (alive) {
 #pragma unroll
         for (int j = 0; j < K; ++j)
             if ((uint32_t)j < k) {
-                out_dist[(size_t)src * k + j] = kb.d[j];
-                out_prim[(size_t)src * k + j] = kb.id[j];
+                out_dist[(size_t)src * k + j] = acc.d[j];
+                out_prim[(size_t)src * k + j] = acc.id[j];
             }
     }
 }
@@ -384,25 +374,80 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
 //   t = t_min; repeat max_steps times: p = o + d*t; (delta, id) = NN(p);
 //   if delta < eps_hit -> hit at depth t; t = t + delta; if t > t_max -> miss.
 // The previous step's nearest primitive is evaluated first to seed `best`, so
-// the walk only has to visit what can still beat it.
+// the walk only has to visit what can still beat it -- and when the bounds
+// kept from the last walk prove that nothing can, the walk is skipped for the
+// whole wavefront (the result is the same (distance, index) either way).
 // Normal (src/main__.rs:151-161): tetrahedron taps of the HIT primitive only.
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(TreeView T, sdfgpu_camera cam, uint32_t width, uint32_t height,
-                                                     sdfgpu_march_params mp, uint32_t tile_first, uint32_t tile_stride,
-                                                     uint32_t tile_count, uint32_t row_major,
-                                                     uint8_t* __restrict__ o_hit, float* __restrict__ o_depth,
-                                                     float* __restrict__ o_normal, uint32_t* __restrict__ o_prim,
-                                                     sdfgpu_stats* __restrict__ st) {
+//
+// Ray compaction.  Step counts per ray are heavy-tailed (median 27, 1 % above
+// 100 on the 10k scene), so a wavefront that keeps its 64 rays to the end runs
+// mostly empty.  The march is therefore cut into PASSES over step ranges
+// [b0,b1), [b1,b2), ...: rays still marching at the end of a pass store 16
+// bytes of state, compacted per wavefront; a one-workgroup scan turns the
+// per-wavefront survivor counts into offsets; the next pass packs survivors,
+// in the same spatial order, 64 to a wavefront.  No host synchronisation
+// between passes (grids are sized for the worst case, empty wavefronts exit).
+struct RayState {
+    float t;
+    float budget;
+    uint32_t last;
+    uint32_t slot;   // tile_local * 64 + lane of the pixel
+};
+static_assert(sizeof(RayState) == 16, "RayState is one 16-byte access");
+
+struct PassArgs {
+    uint32_t step_begin, step_end;
+    uint32_t final_pass;              // rays alive after step_end - 1 are misses
+    const RayState* in_state;         // pass > 0: survivors of the previous pass, [src_wave*64 + rank]
+    const uint32_t* in_offsets;       // exclusive scan of the previous pass's per-wave counts
+    const uint32_t* in_hdr;           // {number of source waves, total survivors}
+    RayState* out_state;
+    uint32_t* out_counts;
+};
+
+template <int MODE, bool COUNT, bool FIRST>
+__global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_camera cam, uint32_t width, uint32_t height,
+                                                          sdfgpu_march_params mp, uint32_t tile_first,
+                                                          uint32_t tile_stride, uint32_t tile_count, uint32_t row_major,
+                                                          PassArgs pa, uint8_t* __restrict__ o_hit,
+                                                          float* __restrict__ o_depth, float* __restrict__ o_normal,
+                                                          uint32_t* __restrict__ o_prim, sdfgpu_stats* __restrict__ st) {
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* stk = smem + wave * T.depth * 64u;
-    const uint32_t tile_local = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
-    if (tile_local >= tile_count) return;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+
+    float t = mp.t_min, budget = 0.f;
+    uint32_t last = SDF_NO_PRIM, slot = 0;
+    bool alive;
+    if constexpr (FIRST) {
+        if (wave_id >= tile_count) return;
+        slot = wave_id * 64u + lane;
+        alive = true;
+    } else {
+        const uint32_t n_src = pa.in_hdr[0], total = pa.in_hdr[1];
+        if (wave_id * 64u >= total) return;
+        const uint32_t j = wave_id * 64u + lane;
+        alive = j < total;
+        if (alive) {
+            // source wave w: offsets[w] <= j < offsets[w+1]
+            uint32_t lo = 0, hi = n_src;
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (pa.in_offsets[mid] <= j) lo = mid; else hi = mid;
+            }
+            const RayState rs = pa.in_state[(size_t)lo * 64u + (j - pa.in_offsets[lo])];
+            t = rs.t; budget = rs.budget; last = rs.last; slot = rs.slot;
+        }
+    }
+    const uint32_t tile_local = slot >> 6, pl = slot & 63u;
     const uint32_t tile = tile_first + tile_local * tile_stride;
     const uint32_t tiles_x = (width + 7u) >> 3;
     const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    const uint32_t x = tx * 8u + (pl & 7u), y = ty * 8u + (pl >> 3);
     const bool inside = x < width && y < height;
+    const bool mine = alive;          // this lane carries a ray (or, FIRST, an edge slot) into the pass
+    alive = alive && inside;
 
     // ray through the pixel centre: pw = (origin + du*x) + dv*y ; d = (pw - eye)/|pw - eye|
     const float fx = (float)x, fy = (float)y;
@@ -415,32 +460,49 @@ __global__ __launch_bounds__(256) void render_kernel(TreeView T, sdfgpu_camera c
     dy = dy / dl;
     dz = dz / dl;
 
-    float t = mp.t_min;
-    bool alive = inside;
     bool hit = false;
     uint32_t hit_prim = SDF_NO_PRIM;
-    uint32_t last = SDF_NO_PRIM;
     uint32_t steps = 0;
     float px = 0.f, py = 0.f, pz = 0.f;
+    // `budget`: proven lower bound, at the current point, on the distance of every
+    // primitive other than `last`.  While last's own (exactly evaluated) distance
+    // stays below it by more than the rounding margin, `last` is the unique
+    // nearest primitive and the walk can be skipped without changing the result.
+    const float ext = T.skip_ext;
     WaveCounters wc;
 
-    for (uint32_t s = 0; s < mp.max_steps; ++s) {
-        if (__ballot(alive) == 0ull) break;
+    for (uint32_t s = pa.step_begin; s < pa.step_end; ++s) {
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         if (alive) {
             px = ox + dx * t;
             py = oy + dy * t;
             pz = oz + dz * t;
         }
+        const float mg = prune_margin<MODE>(T, px, py, pz);
         float best = __builtin_inff();
         uint32_t bid = SDF_NO_PRIM;
-        if (alive && last != SDF_NO_PRIM) {   // seed: per-lane gather of one 64-byte leaf
+        bool certified = false;
+        if (alive && last != SDF_NO_PRIM) {   // per-lane gather of one 64-byte leaf
             best = leaf_eval(T.leaf + last, px, py, pz);
             bid = last;
+            certified = (best + 2.0f * mg) < budget;
             if constexpr (COUNT) {
                 if (T.leaf[last].kind == SDF_PRIM_SPHERE) wc.lane_sphere += 1; else wc.lane_box += 1;
             }
         }
-        nn_traverse<MODE, COUNT>(T, px, py, pz, alive, best, bid, stk, lane, wc);
+        const bool drive = alive && !certified;
+        if constexpr (COUNT) wc.wave_steps += 1;
+        const unsigned long long dmask = __builtin_amdgcn_ballot_w64(drive);
+        if (dmask != 0ull) {
+            if constexpr (COUNT) wc.wave_walks += 1;
+            AccTracked acc{best, bid, __builtin_inff(), __builtin_inff()};
+            nn_traverse<MODE, COUNT>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
+            best = acc.best;
+            bid = acc.bid;
+            float lb = (MODE == SDFGPU_BOUNDS_OBB) ? acc.lb_key : __builtin_sqrtf(acc.lb_key);
+            lb = __builtin_fminf(lb * 0.9996f, acc.second) - mg;
+            budget = certified ? __builtin_fmaxf(budget, lb) : lb;
+        }
         if (alive) {
             steps += 1;
             last = bid;
@@ -450,6 +512,7 @@ __global__ __launch_bounds__(256) void render_kernel(TreeView T, sdfgpu_camera c
                 alive = false;
             } else {
                 t = t + best;
+                budget = (budget - __builtin_fabsf(best) * 1.000004f) - mg;
                 if (t > mp.t_max) alive = false;
             }
         }
@@ -475,22 +538,65 @@ __global__ __launch_bounds__(256) void render_kernel(TreeView T, sdfgpu_camera c
         }
     }
 
-    if (row_major) {
-        if (inside) {
-            const size_t o = (size_t)y * width + x;
+    // rays that go on to the next pass: 16 bytes of state, compacted per wavefront
+    const bool carry = alive && !pa.final_pass;
+    if (!pa.final_pass) {
+        const unsigned long long cm = __builtin_amdgcn_ballot_w64(carry);
+        if (carry) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+            RayState rs;
+            rs.t = t; rs.budget = budget; rs.last = last; rs.slot = slot;
+            pa.out_state[(size_t)wave_id * 64u + rank] = rs;
+        }
+        if (lane == 0) pa.out_counts[wave_id] = (uint32_t)__popcll(cm);
+    }
+    // rays that ended in this pass (hit, left the scene, or ran out of steps) write their pixel
+    if (mine && !carry) {
+        size_t o;
+        bool wr;
+        if (row_major) { o = (size_t)y * width + x; wr = inside; }
+        else { o = slot; wr = true; }
+        if (wr) {
             o_hit[o] = hit ? 1 : 0;
             if (o_depth) o_depth[o] = hit ? t : __builtin_inff();
             if (o_normal) { o_normal[3 * o] = nx; o_normal[3 * o + 1] = ny; o_normal[3 * o + 2] = nz; }
             if (o_prim) o_prim[o] = hit_prim;
         }
-    } else {
-        const size_t o = (size_t)tile_local * 64u + lane;
-        o_hit[o] = hit ? 1 : 0;
-        if (o_depth) o_depth[o] = hit ? t : __builtin_inff();
-        if (o_normal) { o_normal[3 * o] = nx; o_normal[3 * o + 1] = ny; o_normal[3 * o + 2] = nz; }
-        if (o_prim) o_prim[o] = hit_prim;
     }
-    if constexpr (COUNT) flush_counters(wc, lane, steps, inside ? 1u : 0u, st);
+    if constexpr (COUNT) flush_counters(wc, lane, steps, (FIRST && inside) ? 1u : 0u, st);
+}
+
+// Exclusive scan of the per-wavefront survivor counts of one pass (one
+// workgroup; at most a few hundred thousand entries).  n comes from the
+// previous header (number of waves that could have written a count).
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts, uint32_t n_first,
+                                                           const uint32_t* __restrict__ prev_hdr,
+                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ hdr) {
+    __shared__ uint32_t part[1024];
+    const uint32_t n = prev_hdr ? (prev_hdr[1] + 63u) / 64u : n_first;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's chunk
+    for (uint32_t i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (tid == 1023u) {
+        offsets[n] = part[1023];
+        hdr[0] = n;
+        hdr[1] = part[1023];
+    }
 }
 
 // Tile-compact -> row-major scatter (framebuffer assembly after the gather).
@@ -524,6 +630,7 @@ static TreeView make_view(const DeviceTree& d) {
     v.root = d.root_ref;
     v.depth = d.stack_depth;
     v.margin_T = d.margin_T;
+    v.skip_ext = d.skip_ext;
     return v;
 }
 
@@ -569,30 +676,62 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
                                          : launch_knn_m<SDFGPU_BOUNDS_AABB>(d, pts, order, n, k, out_dist, out_prim, s);
 }
 
-template <bool COUNT>
-static hipError_t launch_render_t(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
+template <int MODE, bool COUNT>
+static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
                                   const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride,
-                                  uint32_t tile_count, bool row_major, uint8_t* hit, float* depth, float* normal,
-                                  uint32_t* prim, sdfgpu_stats* st, hipStream_t s) {
-    if (tile_count == 0) return hipSuccess;
+                                  uint32_t tile_count, bool row_major, const RenderScratch& rs, const uint32_t* bounds,
+                                  uint32_t n_bounds, uint8_t* hit, float* depth, float* normal, uint32_t* prim,
+                                  sdfgpu_stats* st, hipStream_t s) {
     TreeView v = make_view(d);
     dim3 grid((tile_count + 3u) / 4u), block(256);
-    size_t lds = (size_t)4 * d.stack_depth * 64 * sizeof(float);
-    if (d.bounds == SDFGPU_BOUNDS_OBB)
-        render_kernel<SDFGPU_BOUNDS_OBB, COUNT><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
-                                                                        row_major ? 1u : 0u, hit, depth, normal, prim, st);
-    else
-        render_kernel<SDFGPU_BOUNDS_AABB, COUNT><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
-                                                                         row_major ? 1u : 0u, hit, depth, normal, prim, st);
-    return hipGetLastError();
+    const size_t lds = (size_t)4 * d.stack_depth * 64 * sizeof(float);
+    // pass boundaries: 0 = b[0] < b[1] < ... < b[n-1] = max_steps
+    for (uint32_t k = 0; k + 1 < n_bounds; ++k) {
+        PassArgs pa;
+        pa.step_begin = bounds[k];
+        pa.step_end = bounds[k + 1];
+        pa.final_pass = (k + 2 == n_bounds) ? 1u : 0u;
+        pa.in_state = (const RayState*)rs.state[(k + 1) & 1];
+        pa.in_offsets = rs.offsets;
+        pa.in_hdr = rs.hdr[k & 1];
+        pa.out_state = (RayState*)rs.state[k & 1];
+        pa.out_counts = rs.counts;
+        if (k == 0)
+            render_pass_kernel<MODE, COUNT, true><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
+                                                                          row_major ? 1u : 0u, pa, hit, depth, normal, prim, st);
+        else
+            render_pass_kernel<MODE, COUNT, false><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
+                                                                           row_major ? 1u : 0u, pa, hit, depth, normal, prim, st);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (!pa.final_pass) {
+            scan_counts_kernel<<<dim3(1), dim3(1024), 0, s>>>(rs.counts, tile_count, k == 0 ? nullptr : rs.hdr[k & 1], rs.offsets,
+                                                              rs.hdr[(k + 1) & 1]);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+size_t render_scratch_bytes(uint32_t tile_count, size_t* state_bytes, size_t* count_bytes) {
+    *state_bytes = (size_t)tile_count * 64u * sizeof(RayState);
+    *count_bytes = ((size_t)tile_count + 1u) * sizeof(uint32_t);
+    return 2 * *state_bytes + 2 * *count_bytes + 64;
 }
 
 hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
                          const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
-                         bool row_major, uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st,
-                         hipStream_t s) {
-    return st ? launch_render_t<true>(d, cam, w, h, mp, tile_first, tile_stride, tile_count, row_major, hit, depth, normal, prim, st, s)
-              : launch_render_t<false>(d, cam, w, h, mp, tile_first, tile_stride, tile_count, row_major, hit, depth, normal, prim, nullptr, s);
+                         bool row_major, const RenderScratch& rs, const uint32_t* pass_bounds, uint32_t n_bounds,
+                         uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s) {
+    if (tile_count == 0) return hipSuccess;
+    const bool obb = d.bounds == SDFGPU_BOUNDS_OBB;
+#define SDFGPU_RENDER(MODE, COUNT) \
+    launch_render_m<MODE, COUNT>(d, cam, w, h, mp, tile_first, tile_stride, tile_count, row_major, rs, pass_bounds, n_bounds, \
+                                 hit, depth, normal, prim, st, s)
+    if (st) return obb ? SDFGPU_RENDER(SDFGPU_BOUNDS_OBB, true) : SDFGPU_RENDER(SDFGPU_BOUNDS_AABB, true);
+    return obb ? SDFGPU_RENDER(SDFGPU_BOUNDS_OBB, false) : SDFGPU_RENDER(SDFGPU_BOUNDS_AABB, false);
+#undef SDFGPU_RENDER
 }
 
 hipError_t launch_untile(uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,

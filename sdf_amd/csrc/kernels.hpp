@@ -17,6 +17,7 @@ struct DeviceTree {
     uint32_t stack_depth = 1;
     uint32_t bounds = SDFGPU_BOUNDS_AABB;
     float margin_T = 0.f;
+    float skip_ext = 0.f;
 };
 
 // st != nullptr selects the counting instantiation of the same kernel.
@@ -33,10 +34,22 @@ hipError_t launch_morton_order(const float* pts_xyzw, uint32_t n, const float lo
                                uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* idx_out, void* temp,
                                size_t temp_bytes, hipStream_t s);
 
+// Scratch of the multi-pass march (ray compaction): two state buffers of
+// tile_count*64 16-byte records, per-wave counts and offsets (tile_count+1), two headers.
+struct RenderScratch {
+    void* state[2] = {nullptr, nullptr};
+    uint32_t* counts = nullptr;
+    uint32_t* offsets = nullptr;
+    uint32_t* hdr[2] = {nullptr, nullptr};
+};
+size_t render_scratch_bytes(uint32_t tile_count, size_t* state_bytes, size_t* count_bytes);
+
+// pass_bounds: 0 = b[0] < ... < b[n-1] = max_steps (n >= 2; n == 2 is a single pass).
+// st != nullptr selects the counting instantiation of the same kernels.
 hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
                          const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
-                         bool row_major, uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st,
-                         hipStream_t s);
+                         bool row_major, const RenderScratch& rs, const uint32_t* pass_bounds, uint32_t n_bounds,
+                         uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s);
 
 hipError_t launch_untile(uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
                          const uint8_t* t_hit, const float* t_depth, const float* t_normal, const uint32_t* t_prim,

@@ -104,8 +104,18 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_nearest_stats_dev(self._h, d_pts, n, C.byref(st)))
         return st.as_dict()
 
+    def set_option(self, option, value):
+        self._check(self._lib.sdfgpu_set_option(self._h, option, float(value)))
+
     def set_reorder(self, enabled):
-        self._check(self._lib.sdfgpu_set_reorder(self._h, 1 if enabled else 0))
+        self.set_option(_ffi.OPT_REORDER, 1 if enabled else 0)
+
+    def set_compaction(self, enabled):
+        self.set_option(_ffi.OPT_COMPACTION, 1 if enabled else 0)
+
+    def set_skip_extension(self, value):
+        """0 (default): no widening of the search radius; < 0: half the mean primitive size."""
+        self.set_option(_ffi.OPT_SKIP_EXTENSION, value)
 
     def knn(self, pts_xyzw, k):
         p = np.ascontiguousarray(pts_xyzw, dtype=np.float32).reshape(-1, 4)

@@ -87,5 +87,6 @@ FLOP_NORMAL_TAP = 6  # 3 point offsets + 3 accumulations per tap (leaf evals cou
 def algorithmic_flops(stats: dict) -> int:
     """Algorithmic flops of one launch from the counting kernel's counters
     (lane-level: work done for lanes that were alive)."""
+    per_step = max(stats["steps"], stats["queries"])   # render: every march step; nearest: every query
     return (stats["inner_visits"] * FLOP_INNER + stats["sphere_evals"] * FLOP_SPHERE
-            + stats["box_evals"] * FLOP_BOX + stats["queries"] * FLOP_QUERY)
+            + stats["box_evals"] * FLOP_BOX + per_step * FLOP_QUERY)

@@ -112,3 +112,47 @@ def test_tiles_and_untile_roundtrip(gpu):
         assert np.array_equal(bits(o_depth.cpu().numpy()), bits(full["depth"]))
         assert np.array_equal(bits(o_normal.cpu().numpy().reshape(-1, 3)), bits(full["normal"]))
         assert np.array_equal(o_prim.cpu().numpy().view(np.uint32), full["prim"])
+
+
+@pytest.mark.parametrize("ext", [0.0, -1.0, 0.05, 3.0, 50.0])
+def test_walk_skipping_never_changes_the_frame(gpu, ext):
+    # SDFGPU_OPT_SKIP_EXTENSION only trades walks for proofs; every output stays bit-identical
+    n, w, h = 300, 128, 80
+    buf = S.random_scene_buffer(n, 0x5C1F)
+    cam, mp = scene_camera(n, w, h)
+    ref = O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8)
+    for bounds in (S.BOUNDS_AABB, S.BOUNDS_OBB):
+        gpu.upload_tree(buf, bounds=bounds)
+        gpu.set_skip_extension(ext)
+        _compare(gpu.render(cam, w, h, mp), ref)
+    gpu.set_skip_extension(-1.0)
+
+
+def test_grazing_camera_inside_the_scene(gpu):
+    # camera inside the primitive cloud, long grazing rays: the regime walk skipping is for
+    n, w, h = 400, 96, 64
+    buf = S.random_scene_buffer(n, 0xC0FFEE)
+    L = S.default_extent(n)
+    cam = S.camera_look_at((0.3 * L, 0.1 * L, -0.2 * L), (L, 0.2 * L, 0.9 * L), (0, 1, 0), 1.2, w, h)
+    mp = S.march_params(max_steps=200, eps_hit=1e-4, t_min=0.0, t_max=6 * L, normal_h=1e-3)
+    gpu.upload_tree(buf)
+    st = gpu.render_stats(cam, w, h, mp)
+    assert st["steps"] > st["queries"] > 0          # some steps were proven without a walk
+    _compare(gpu.render(cam, w, h, mp), O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8))
+
+
+@pytest.mark.parametrize("max_steps", [0, 1, 11, 12, 13, 28, 57, 200])
+def test_ray_compaction_is_invisible(gpu, max_steps):
+    # the multi-pass march (SDFGPU_OPT_COMPACTION) re-packs survivors between passes;
+    # pass boundaries at 12/20/28/40/56/80 steps must not show in any output
+    n, w, h = 250, 121, 67
+    buf = S.random_scene_buffer(n, 0xBEEF)
+    L = S.default_extent(n)
+    cam = S.camera_look_at((0.2 * L, 0.1 * L, -1.2 * L), (0, 0, 0), (0, 1, 0), 1.0, w, h)
+    mp = S.march_params(max_steps=max_steps, eps_hit=1e-3, t_min=0.0, t_max=6 * L, normal_h=1e-4)
+    ref = O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8)
+    gpu.upload_tree(buf)
+    for on in (True, False):
+        gpu.set_compaction(on)
+        _compare(gpu.render(cam, w, h, mp), ref)
+    gpu.set_compaction(True)
