@@ -184,6 +184,14 @@ int sdfgpu_knn(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n, uint32_t k,
 int sdfgpu_knn_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n, uint32_t k,
                    float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
 
+/* The two bounds of the reference's union prune for one box at n host points:
+ * out_min = mindist (faux_shader.rs:54-58 = SdfBoundingBox::distance_to,
+ * obb.rs:294-300), out_max = maxdist (faux_shader.rs:39-52 = max_distance,
+ * obb.rs:302-307), in the reference's own operation order on all four lanes.
+ * Needs no uploaded tree. */
+int sdfgpu_box_bounds(sdfgpu_ctx* ctx, const SdfBoundingBoxBlock* box, const float* pts_xyzw,
+                      size_t n, float* out_min, float* out_max);
+
 /* ---- sphere trace + normals -------------------------------------------- */
 /* Full frame, host pointers (each may be NULL except hit):
  *   hit[w*h] u8, depth[w*h] f32 (+inf on miss), normal_xyz[3*w*h] f32

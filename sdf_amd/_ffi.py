@@ -139,6 +139,7 @@ GPU_SYMBOLS = {
     "sdfgpu_set_option": (_i, [_vp, _i, C.c_double]),
     "sdfgpu_knn": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "sdfgpu_knn_dev": (_i, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),
+    "sdfgpu_box_bounds": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "sdfgpu_render": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _vp, _vp, _vp, _vp]),
     "sdfgpu_render_dev": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _vp, _vp, _vp, _vp, _vp]),
     "sdfgpu_render_tiles_dev": (

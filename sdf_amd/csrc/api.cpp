@@ -74,6 +74,7 @@ void free_tree(sdfgpu_ctx* c) {
     if (c->tree.leaf) (void)hipFree(c->tree.leaf);
     if (c->tree.inner) (void)hipFree(c->tree.inner);
     if (c->tree.inner_obb) (void)hipFree(c->tree.inner_obb);
+    if (c->tree.gen) (void)hipFree(c->tree.gen);
     c->tree = DeviceTree();
     c->has_tree = false;
 }
@@ -97,7 +98,7 @@ int check_march(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
 constexpr size_t REORDER_MIN_POINTS = 2048;
 int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const uint32_t** order) {
     *order = nullptr;
-    if (!c->reorder || n < REORDER_MIN_POINTS) return SDFGPU_OK;
+    if (!c->reorder || n < REORDER_MIN_POINTS || c->tree.gen) return SDFGPU_OK;
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
         // twice the scene box: queries usually sit around the scene; outliers are clamped
@@ -255,6 +256,8 @@ int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOper
     if ((rc = upload_vec(c, t.leaves, &c->tree.leaf)) != SDFGPU_OK) return rc;
     if ((rc = upload_vec(c, t.inner, &c->tree.inner)) != SDFGPU_OK) return rc;
     if ((rc = upload_vec(c, t.inner_obb, &c->tree.inner_obb)) != SDFGPU_OK) return rc;
+    if ((rc = upload_vec(c, t.gen, &c->tree.gen)) != SDFGPU_OK) return rc;
+    c->tree.n_gen = (uint32_t)t.gen.size();
     c->tree.root_ref = t.root_ref;
     c->tree.stack_depth = t.stack_depth;
     c->tree.bounds = t.info.bounds;
@@ -372,6 +375,27 @@ int sdfgpu_knn(sdfgpu_ctx* c, const float* pts, size_t n, uint32_t k, float* out
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out_dist, c->out_a.p, n * k * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_prim, c->out_b.p, n * k * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_box_bounds(sdfgpu_ctx* c, const SdfBoundingBoxBlock* box, const float* pts, size_t n, float* out_min,
+                      float* out_max) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n == 0) return SDFGPU_OK;
+    if (!box || !pts || !out_min || !out_max) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null pointer");
+    if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
+    int rc;
+    if ((rc = reserve(c, c->in, n * 16)) || (rc = reserve(c, c->out_a, n * 4)) || (rc = reserve(c, c->out_b, n * 4)) ||
+        (rc = reserve(c, c->stats, sizeof(SdfBoundingBoxBlock))))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->in.p, pts, n * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->stats.p, box, sizeof(SdfBoundingBoxBlock), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_box_bounds((const SdfBoundingBoxBlock*)c->stats.p, (const float*)c->in.p, (uint32_t)n,
+                                 (float*)c->out_a.p, (float*)c->out_b.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_min, c->out_a.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_max, c->out_b.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SDFGPU_OK;
 }

@@ -278,9 +278,39 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     }
     if (max_level - 1 > 63) return fail(err, SDFGPU_ERR_TOO_DEEP, "tree depth %u exceeds the 64-entry wave stack", max_level);
 
-    if (!identity_inner || !exact_rows)
-        return fail(err, SDFGPU_ERR_UNSUPPORTED_OP,
-                    "tree needs the general path (non-identity internal trans_inverse or projective leaf rows), not built yet");
+    if (!identity_inner || !exact_rows) {
+        // General path: no pruning, the literal per-level point chain.
+        if (bounds == SDFGPU_BOUNDS_AABB || bounds == SDFGPU_BOUNDS_OBB)
+            return fail(err, SDFGPU_ERR_BAD_TREE,
+                        "pruned bounds need identity internal trans_inverse and affine leaf rows; use AUTO or NONE");
+        if (max_level > GEN_MAX_LEVELS)
+            return fail(err, SDFGPU_ERR_TOO_DEEP, "general path holds %u levels, tree has %u", GEN_MAX_LEVELS, max_level);
+        out->gen.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            GpuGenNode& g = out->gen[i];
+            std::memset(&g, 0, sizeof g);
+            std::memcpy(g.m, dt[i].bounding_box.trans_inverse.m, 64);
+            g.is_leaf = dt[i].is_primitive;
+            g.level = dt[i].level;
+            g.len = dt[i].len;
+            g.kind = dt[i].op_code;
+            g.prim = c.prim_id[i];
+            if (dt[i].is_primitive) {
+                if (dt[i].op_code == SDF_PRIM_SPHERE) g.param[0] = dt[i].op_specific.floats[0];
+                else for (int a = 0; a < 3; ++a) g.param[a] = dt[i].op_specific.vec4s[0].v[a];
+            }
+        }
+        sdfgpu_tree_info& gi = out->info;
+        gi.n_prims = n_prims;
+        gi.n_inner = n_inner;
+        gi.max_level = max_level;
+        gi.bounds = SDFGPU_BOUNDS_NONE;
+        gi.identity_inner = identity_inner ? 1 : 0;
+        gi.rigid_leaves = rigid ? 1 : 0;
+        gi.device_bytes = out->gen.size() * sizeof(GpuGenNode);
+        out->stack_depth = max_level + 1;
+        return SDFGPU_OK;
+    }
 
     uint32_t mode = bounds;
     if (mode == SDFGPU_BOUNDS_AUTO) mode = rigid ? SDFGPU_BOUNDS_AABB : SDFGPU_BOUNDS_NONE;

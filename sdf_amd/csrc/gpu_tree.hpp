@@ -51,7 +51,25 @@ struct alignas(64) GpuInnerObb {
 };
 static_assert(sizeof(GpuInnerObb) == 128, "GpuInnerObb is two 64-byte lines");
 
+// General path (any union tree the reference state machine accepts: internal
+// nodes with a non-identity trans_inverse, projective rows): every node in
+// pre-order with its full 4x4 trans_inverse, walked exhaustively with a
+// per-level point stack -- the literal point chain of faux_shader.rs:160-178.
+constexpr uint32_t GEN_MAX_LEVELS = 32;
+struct alignas(64) GpuGenNode {
+    float m[16];       // trans_inverse, column-major as in the buffer
+    float param[3];
+    uint32_t kind;     // primitive kind (leaves)
+    uint32_t is_leaf;
+    uint32_t level;    // root = 1
+    uint32_t prim;     // primitive id (leaves)
+    uint32_t len;
+    uint32_t pad[8];
+};
+static_assert(sizeof(GpuGenNode) == 128, "GpuGenNode is two 64-byte lines");
+
 struct CompactTree {
+    std::vector<GpuGenNode> gen;        // general path (empty otherwise)
     std::vector<GpuLeaf> leaves;
     std::vector<GpuInner> inner;        // AABB mode
     std::vector<GpuInnerObb> inner_obb; // OBB mode

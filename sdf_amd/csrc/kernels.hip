@@ -620,6 +620,177 @@ __global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t he
     if (o_prim) o_prim[o] = t_prim[s];
 }
 
+// ------------------------------------------------------- general path -----
+// Any union tree the reference state machine accepts (non-identity internal
+// trans_inverse, projective rows): the literal point chain of
+// faux_shader.rs:160-178 -- every node's 4x4 trans_inverse applied to the
+// 4-component point handed down by its parent (glam Mat4*Vec4 order), one
+// rounded mat-vec per level, primitives evaluated on xyz.  No pruning: the
+// bounds of such buffers live in frames the children are not re-based into
+// (SURVEY C-3), so the walk is the exhaustive one, Theta(N) per query like the
+// reference's own.  Wave-uniform node index, per-level points in LDS.
+struct P4 { float x, y, z, w; };
+
+__device__ __forceinline__ P4 mat4_mul(const float* __restrict__ c, P4 p) {
+    P4 r;
+    r.x = ((c[0] * p.x + c[4] * p.y) + c[8] * p.z) + c[12] * p.w;
+    r.y = ((c[1] * p.x + c[5] * p.y) + c[9] * p.z) + c[13] * p.w;
+    r.z = ((c[2] * p.x + c[6] * p.y) + c[10] * p.z) + c[14] * p.w;
+    r.w = ((c[3] * p.x + c[7] * p.y) + c[11] * p.z) + c[15] * p.w;
+    return r;
+}
+
+// only: SDF_NO_PRIM = every primitive, else just that one (normal taps).
+template <class Acc>
+__device__ __forceinline__ void walk_general(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, uint32_t only,
+                                             Acc& acc, float4* __restrict__ stk, uint32_t lane) {
+    stk[lane] = make_float4(p.x, p.y, p.z, p.w);
+    for (uint32_t i = 0; i < n; ++i) {
+        const GpuGenNode* __restrict__ N = nodes + i;
+        const uint32_t lv = N->level;
+        const float4 q4 = stk[(lv - 1u) * 64u + lane];
+        const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+        if (N->is_leaf) {
+            const float d = prim_value(N->kind, N->param[0], N->param[1], N->param[2], r.x, r.y, r.z);
+            if (only == SDF_NO_PRIM || only == N->prim) acc.offer(d, N->prim);
+        } else {
+            stk[lv * 64u + lane] = make_float4(r.x, r.y, r.z, r.w);   // downtree_dispatch, union: [p, p]
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __restrict__ nodes, uint32_t n_nodes,
+                                                           const float4* __restrict__ pts, uint32_t n, uint32_t k,
+                                                           float* __restrict__ out_dist, uint32_t* __restrict__ out_prim) {
+    extern __shared__ float4 gstk[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64u + lane;
+    const bool alive = i < n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (alive) p = pts[i];
+    if constexpr (K == 1) {
+        AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
+        walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (alive) {
+            out_dist[i] = acc.best;
+            if (out_prim) out_prim[i] = acc.bid;
+        }
+    } else {
+        AccK<K> acc;
+        acc.init();
+        walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (alive) {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if ((uint32_t)j < k) {
+                    out_dist[(size_t)i * k + j] = acc.d[j];
+                    out_prim[(size_t)i * k + j] = acc.id[j];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __restrict__ nodes, uint32_t n_nodes,
+                                                            sdfgpu_camera cam, uint32_t width, uint32_t height,
+                                                            sdfgpu_march_params mp, uint32_t tile_first, uint32_t tile_stride,
+                                                            uint32_t tile_count, uint32_t row_major,
+                                                            uint8_t* __restrict__ o_hit, float* __restrict__ o_depth,
+                                                            float* __restrict__ o_normal, uint32_t* __restrict__ o_prim) {
+    extern __shared__ float4 gstk[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile_local = blockIdx.x;
+    if (tile_local >= tile_count) return;
+    const uint32_t tile = tile_first + tile_local * tile_stride;
+    const uint32_t tiles_x = (width + 7u) >> 3;
+    const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u), y = (tile / tiles_x) * 8u + (lane >> 3);
+    const bool inside = x < width && y < height;
+    const float fx = (float)x, fy = (float)y;
+    const float ox = cam.eye[0], oy = cam.eye[1], oz = cam.eye[2];
+    float dx = ((cam.origin[0] + cam.du[0] * fx) + cam.dv[0] * fy) - ox;
+    float dy = ((cam.origin[1] + cam.du[1] * fx) + cam.dv[1] * fy) - oy;
+    float dz = ((cam.origin[2] + cam.du[2] * fx) + cam.dv[2] * fy) - oz;
+    const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
+    dx = dx / dl; dy = dy / dl; dz = dz / dl;
+    float t = mp.t_min;
+    bool alive = inside, hit = false;
+    uint32_t hit_prim = SDF_NO_PRIM;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    for (uint32_t s = 0; s < mp.max_steps; ++s) {
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+        if (alive) { px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t; }
+        AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
+        walk_general(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (alive) {
+            if (acc.best < mp.eps_hit) { hit = true; hit_prim = acc.bid; alive = false; }
+            else { t = t + acc.best; if (t > mp.t_max) alive = false; }
+        }
+    }
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+        const float h = mp.normal_h;
+        const float sgn[4][3] = {{1.f, -1.f, -1.f}, {-1.f, -1.f, 1.f}, {-1.f, 1.f, -1.f}, {1.f, 1.f, 1.f}};
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
+            walk_general(nodes, n_nodes, P4{px + sgn[j][0] * h, py + sgn[j][1] * h, pz + sgn[j][2] * h, 1.0f},
+                         hit ? hit_prim : 0xFFFFFFFEu, acc, gstk, lane);
+            f[j] = acc.best;
+        }
+        if (hit) {
+            const float sx = ((f[0] - f[1]) - f[2]) + f[3];
+            const float sy = ((-f[0] - f[1]) + f[2]) + f[3];
+            const float sz = ((-f[0] + f[1]) - f[2]) + f[3];
+            const float nl = __builtin_sqrtf((sx * sx + sy * sy) + sz * sz);
+            if (nl > 0.f) { nx = sx / nl; ny = sy / nl; nz = sz / nl; }
+        }
+    }
+    size_t o;
+    bool wr;
+    if (row_major) { o = (size_t)y * width + x; wr = inside; }
+    else { o = (size_t)tile_local * 64u + lane; wr = true; }
+    if (wr) {
+        o_hit[o] = hit ? 1 : 0;
+        if (o_depth) o_depth[o] = hit ? t : __builtin_inff();
+        if (o_normal) { o_normal[3 * o] = nx; o_normal[3 * o + 1] = ny; o_normal[3 * o + 2] = nz; }
+        if (o_prim) o_prim[o] = hit_prim;
+    }
+}
+
+// ------------------------------------------- bounds of faux_shader.rs:39-58 --
+// MINDIST (A-2) and MAXDIST (A-3) exactly as written, all four lanes:
+//   mindist: t = full_inverse * p; q = (|t| - 1) * scale;
+//            |max(q,0)|_4 (glam dot4 order (x^2+z^2)+(y^2+w^2)) + min(max(qx,max(qy,qz)),0)
+//   maxdist: max over the 8 corners v of |matrix * v - p|_4 (CmpFloat max).
+__device__ __forceinline__ float len4_glam(float x, float y, float z, float w) {
+    return __builtin_sqrtf((x * x + z * z) + (y * y + w * w));
+}
+__global__ __launch_bounds__(256) void box_bounds_kernel(const SdfBoundingBoxBlock* __restrict__ box,
+                                                         const float4* __restrict__ pts, uint32_t n,
+                                                         float* __restrict__ out_min, float* __restrict__ out_max) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p4 = pts[i];
+    const P4 p{p4.x, p4.y, p4.z, p4.w};
+    const P4 t = mat4_mul(box->full_inverse.m, p);
+    const float qx = (__builtin_fabsf(t.x) - 1.0f) * box->scale.v[0];
+    const float qy = (__builtin_fabsf(t.y) - 1.0f) * box->scale.v[1];
+    const float qz = (__builtin_fabsf(t.z) - 1.0f) * box->scale.v[2];
+    const float qw = (__builtin_fabsf(t.w) - 1.0f) * box->scale.v[3];
+    const float l = len4_glam(qx > 0.f ? qx : 0.f, qy > 0.f ? qy : 0.f, qz > 0.f ? qz : 0.f, qw > 0.f ? qw : 0.f);
+    out_min[i] = l + __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
+    float best = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const P4 v{(c & 1) ? -1.f : 1.f, (c & 2) ? -1.f : 1.f, (c & 4) ? -1.f : 1.f, 1.f};
+        const P4 m = mat4_mul(box->matrix.m, v);
+        const float d = len4_glam(m.x - p.x, m.y - p.y, m.z - p.z, m.w - p.w);
+        best = (c == 0) ? d : (best > d ? best : d);
+    }
+    out_max[i] = best;
+}
+
 // --------------------------------------------------------------- launch ---
 
 static TreeView make_view(const DeviceTree& d) {
@@ -648,8 +819,23 @@ static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const 
     return hipGetLastError();
 }
 
+static size_t general_lds(const DeviceTree& d) { return (size_t)(d.stack_depth + 1u) * 64u * sizeof(float4); }
+
+hipError_t launch_box_bounds(const SdfBoundingBoxBlock* d_box, const float* d_pts, uint32_t n, float* d_min, float* d_max,
+                             hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    box_bounds_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, s>>>(d_box, (const float4*)d_pts, n, d_min, d_max);
+    return hipGetLastError();
+}
+
 hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, float* out_dist,
                           uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
+    if (d.gen) {   // general path: exhaustive literal chain (no counters, no reordering needed)
+        if (n == 0) return hipSuccess;
+        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, (const float4*)pts, n, 1,
+                                                                                       out_dist, out_prim);
+        return hipGetLastError();
+    }
     return st ? launch_nearest_t<true>(d, pts, order, n, out_dist, out_prim, st, s)
               : launch_nearest_t<false>(d, pts, order, n, out_dist, out_prim, nullptr, s);
 }
@@ -672,6 +858,16 @@ static hipError_t launch_knn_m(const DeviceTree& d, const float* pts, const uint
 hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, uint32_t k,
                       float* out_dist, uint32_t* out_prim, hipStream_t s) {
     if (n == 0 || k == 0) return hipSuccess;
+    if (d.gen) {
+        dim3 grid((n + 63u) / 64u), block(64);
+        const size_t lds = general_lds(d);
+        const float4* p4 = (const float4*)pts;
+        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
+        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
+        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
+        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
+        return hipGetLastError();
+    }
     return d.bounds == SDFGPU_BOUNDS_OBB ? launch_knn_m<SDFGPU_BOUNDS_OBB>(d, pts, order, n, k, out_dist, out_prim, s)
                                          : launch_knn_m<SDFGPU_BOUNDS_AABB>(d, pts, order, n, k, out_dist, out_prim, s);
 }
@@ -725,6 +921,12 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
                          bool row_major, const RenderScratch& rs, const uint32_t* pass_bounds, uint32_t n_bounds,
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s) {
     if (tile_count == 0) return hipSuccess;
+    if (d.gen) {
+        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, cam, w, h, mp, tile_first,
+                                                                                tile_stride, tile_count, row_major ? 1u : 0u,
+                                                                                hit, depth, normal, prim);
+        return hipGetLastError();
+    }
     const bool obb = d.bounds == SDFGPU_BOUNDS_OBB;
 #define SDFGPU_RENDER(MODE, COUNT) \
     launch_render_m<MODE, COUNT>(d, cam, w, h, mp, tile_first, tile_stride, tile_count, row_major, rs, pass_bounds, n_bounds, \

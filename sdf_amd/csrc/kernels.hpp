@@ -13,6 +13,8 @@ struct DeviceTree {
     GpuLeaf* leaf = nullptr;
     GpuInner* inner = nullptr;
     GpuInnerObb* inner_obb = nullptr;
+    GpuGenNode* gen = nullptr;          // general path: all nodes, pre-order
+    uint32_t n_gen = 0;
     uint32_t root_ref = REF_NONE;
     uint32_t stack_depth = 1;
     uint32_t bounds = SDFGPU_BOUNDS_AABB;
@@ -50,6 +52,10 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
                          const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
                          bool row_major, const RenderScratch& rs, const uint32_t* pass_bounds, uint32_t n_bounds,
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s);
+
+// MINDIST / MAXDIST of one box at n points (faux_shader.rs:39-58, all four lanes).
+hipError_t launch_box_bounds(const SdfBoundingBoxBlock* d_box, const float* d_pts_xyzw, uint32_t n, float* d_min,
+                             float* d_max, hipStream_t s);
 
 hipError_t launch_untile(uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
                          const uint8_t* t_hit, const float* t_depth, const float* t_normal, const uint32_t* t_prim,

@@ -128,6 +128,15 @@ class SdfGpu:
     def knn_dev(self, d_pts, n, k, d_dist, d_prim, stream=0):
         self._check(self._lib.sdfgpu_knn_dev(self._h, d_pts, n, k, d_dist, d_prim, stream))
 
+    def box_bounds(self, box_block, pts_xyzw):
+        """MINDIST / MAXDIST (faux_shader.rs:39-58) of one SdfBoundingBoxBlock at the points."""
+        b = np.ascontiguousarray(np.array([box_block], dtype=_ffi.BBOX_DTYPE))
+        p = np.ascontiguousarray(pts_xyzw, dtype=np.float32).reshape(-1, 4)
+        lo = np.empty(p.shape[0], np.float32)
+        hi = np.empty(p.shape[0], np.float32)
+        self._check(self._lib.sdfgpu_box_bounds(self._h, b.ctypes.data, p.ctypes.data, p.shape[0], lo.ctypes.data, hi.ctypes.data))
+        return lo, hi
+
     # ---- sphere trace -----------------------------------------------------
     def render(self, cam, width, height, mp):
         np_ = width * height

@@ -89,10 +89,36 @@ def test_three_children_rejected():
     assert rc == _ffi.ERR_BAD_TREE and "two children" in msg
 
 
-def test_non_identity_inner_transform_needs_general_path():
+def test_non_identity_inner_transform_takes_the_general_path():
+    # SURVEY C-3: the crate's literal merged boxes re-base the point; such buffers are
+    # walked exhaustively with the per-level point chain (no pruning is valid for them)
     buf = S.random_scene(9, 3, opts={"pca_trans_inverse": True}).expanded().make_buffer()
-    rc, _, msg = S.compact_host(buf)
-    assert rc == _ffi.ERR_UNSUPPORTED_OP and "general path" in msg
+    rc, info, msg = S.compact_host(buf)
+    assert rc == 0 and info.bounds == S.BOUNDS_NONE and info.identity_inner == 0, msg
+    assert info.device_bytes == 128 * buf.buffer_len
+    for b in (S.BOUNDS_AABB, S.BOUNDS_OBB):
+        rc, _, msg = S.compact_host(buf, bounds=b)
+        assert rc == _ffi.ERR_BAD_TREE and "identity" in msg
+
+
+def test_general_path_depth_limit():
+    buf = S.random_scene(9, 3, opts={"pca_trans_inverse": True}).expanded().make_buffer()
+    dt, ut = buf.downtree_buffer.copy(), buf.uptree_buffer.copy()
+    # a 40-level chain of one-child unions above the tree
+    chain = np.zeros(40, _ffi.DT_DTYPE)
+    chain["level"] = np.arange(1, 41)
+    chain["len"] = len(dt) + 39 - np.arange(40)
+    chain["bounding_box"] = dt["bounding_box"][0]
+    chain["parent_is_union"] = 1
+    chain["parent_is_union"][0] = 0
+    dt["level"] += 40
+    dt["parent_is_union"][0] = 1
+    ut["level"] += 40
+    uchain = np.zeros(40, _ffi.UT_DTYPE)
+    uchain["level"] = np.arange(40, 0, -1)
+    big = S.SdfTreeBuffer(np.concatenate([chain, dt]), np.concatenate([ut, uchain]))
+    rc, _, msg = S.compact_host(big)
+    assert rc == _ffi.ERR_TOO_DEEP and "general path" in msg
 
 
 def test_non_rigid_leaf_falls_back_to_no_pruning():

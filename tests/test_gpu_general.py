@@ -1,0 +1,95 @@
+"""GPU parity on the general path (non-identity internal trans_inverse, projective
+rows: SURVEY C-3) and of the reference's bounds MINDIST / MAXDIST (A-2, A-3)."""
+import math
+
+import numpy as np
+import pytest
+
+import sdf_amd as S
+from sdf_amd import _ffi
+from oracle import oracle as O
+from conftest import bits, make_points
+
+pytestmark = pytest.mark.gpu
+
+
+def pca_scene(n, seed):
+    return S.random_scene(n, seed, opts={"pca_trans_inverse": True}).expanded().make_buffer()
+
+
+@pytest.mark.parametrize("n", [2, 3, 9, 64, 300])
+def test_general_nearest_and_knn(gpu, n):
+    buf = pca_scene(n, 0x6E00 + n)
+    info = gpu.upload_tree(buf)
+    assert info.identity_inner == 0 and info.bounds == S.BOUNDS_NONE
+    pts = make_points(2000, S.default_extent(n), n)
+    d, i = gpu.nearest(pts)
+    d0, i0 = O.nearest(buf, pts, O.MODE_EXHAUSTIVE, threads=8)
+    assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+    for k in (3, 8):
+        kd, ki = gpu.knn(pts[:500], k)
+        kd0, ki0 = O.knn(buf, pts[:500], k, threads=8)
+        assert np.array_equal(bits(kd), bits(kd0)) and np.array_equal(ki, ki0)
+
+
+def test_general_differs_from_identity_scene(gpu):
+    # the re-basing really is applied: same primitives, different answers than the identity build
+    a = S.random_scene_buffer(20, 5)
+    b = pca_scene(20, 5)
+    pts = make_points(500, S.default_extent(20), 1)
+    gpu.upload_tree(a)
+    da, _ = gpu.nearest(pts)
+    gpu.upload_tree(b)
+    db, _ = gpu.nearest(pts)
+    assert not np.array_equal(bits(da), bits(db))
+
+
+def test_projective_leaf_row(gpu):
+    # bottom-right element 1 + ulp: w is carried through the chain like the reference does
+    buf = S.random_scene_buffer(12, 8)
+    dt = buf.downtree_buffer.copy()
+    leaf = int(np.flatnonzero(dt["is_primitive"])[3])
+    dt["bounding_box"]["trans_inverse"][leaf][15] = np.nextafter(np.float32(1), np.float32(2))
+    inner = int(np.flatnonzero(dt["is_primitive"] == 0)[1])
+    dt["bounding_box"]["trans_inverse"][inner][15] = np.float32(0.75)     # children see w = 0.75
+    buf2 = S.SdfTreeBuffer(dt, buf.uptree_buffer)
+    info = gpu.upload_tree(buf2)
+    assert info.bounds == S.BOUNDS_NONE
+    pts = make_points(1500, S.default_extent(12), 2)
+    d, i = gpu.nearest(pts)
+    d0, i0 = O.nearest(buf2, pts, O.MODE_EXHAUSTIVE)
+    assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+
+
+def test_general_render(gpu):
+    n, w, h = 25, 48, 32
+    buf = pca_scene(n, 77)
+    L = S.default_extent(n)
+    cam = S.camera_look_at((0, 0, -3.5 * L), (0, 0, 0), (0, 1, 0), math.pi / 3, w, h)
+    mp = S.march_params(max_steps=96, eps_hit=1e-3, t_min=0.0, t_max=10 * L, normal_h=1e-3)
+    gpu.upload_tree(buf)
+    img = gpu.render(cam, w, h, mp)
+    ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
+    assert ref["hit"].sum() > 0
+    assert np.array_equal(img["hit"], ref["hit"]) and np.array_equal(img["prim"], ref["prim"])
+    assert np.array_equal(bits(img["depth"]), bits(ref["depth"]))
+    assert np.array_equal(bits(img["normal"]), bits(ref["normal"]))
+
+
+def test_box_bounds_match_the_reference_formulas(gpu):
+    # A-2 mindist (faux_shader.rs:54-58) and A-3 maxdist (:39-52), bit for bit
+    buf = S.random_scene_buffer(60, 3)
+    pts = make_points(4096, S.default_extent(60), 4, scale=1.5)
+    for node in (0, 1, 2, 17, 60, 118):
+        lo, hi = gpu.box_bounds(buf.downtree_buffer["bounding_box"][node], pts)
+        lo0, hi0 = O.bounds(buf, node, pts)
+        assert np.array_equal(bits(lo), bits(lo0)) and np.array_equal(bits(hi), bits(hi0))
+    # a box with a projective / scaled w lane exercises all four lanes
+    blk = buf.downtree_buffer["bounding_box"][5].copy()
+    blk["scale"][3] = 0.5
+    blk["full_inverse"][15] = 1.25
+    odd = S.SdfTreeBuffer(buf.downtree_buffer.copy(), buf.uptree_buffer)
+    odd.downtree_buffer["bounding_box"][5] = blk
+    lo, hi = gpu.box_bounds(blk, pts)
+    lo0, hi0 = O.bounds(odd, 5, pts)
+    assert np.array_equal(bits(lo), bits(lo0)) and np.array_equal(bits(hi), bits(hi0))
