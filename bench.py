@@ -294,6 +294,7 @@ def main():
                 "walks_per_ray": st["queries"] / max(1, st["rays"]),
                 "wave_steps": st["wave_steps"], "wave_walks": st["wave_walks"],
                 "inner_visits_per_walk": st["inner_visits"] / max(1, st["queries"]),
+                "inner_needed_per_walk": st["inner_needed"] / max(1, st["queries"]),
                 "leaf_evals_per_step": (st["sphere_evals"] + st["box_evals"]) / max(1, st["steps"]),
                 "wave_inner_visits": st["wave_inner"], "wave_leaf_visits": st["wave_leaf"],
                 "queries": st["queries"],

@@ -113,6 +113,7 @@ typedef struct sdfgpu_stats {
     uint64_t rays;
     uint64_t wave_steps;     /* march steps per wavefront */
     uint64_t wave_walks;     /* ... of which needed a tree walk (the rest were proven by kept bounds) */
+    uint64_t inner_needed;   /* internal-node visits a lane itself needed (<= inner_visits: the wave visits the union) */
 } sdfgpu_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

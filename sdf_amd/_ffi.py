@@ -106,6 +106,7 @@ class Stats(C.Structure):
         ("rays", C.c_uint64),
         ("wave_steps", C.c_uint64),
         ("wave_walks", C.c_uint64),
+        ("inner_needed", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -115,7 +115,7 @@ __device__ __forceinline__ float prune_margin(const TreeView& T, float px, float
 
 struct WaveCounters {
     uint32_t wave_inner = 0, wave_leaf = 0, wave_steps = 0, wave_walks = 0;
-    uint32_t lane_inner = 0, lane_sphere = 0, lane_box = 0, lane_queries = 0;
+    uint32_t lane_inner = 0, lane_sphere = 0, lane_box = 0, lane_queries = 0, lane_needed = 0;
 };
 
 // Prune threshold for the current best.  AABB mode compares squared
@@ -220,6 +220,7 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
             const float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(needed<MODE>(k0, thr)) & drive;
             const unsigned long long m1 = __builtin_amdgcn_ballot_w64(needed<MODE>(k1, thr)) & drive;
+            if constexpr (COUNT) wc.lane_needed += (unsigned)(((m0 | m1) >> lane) & 1ull);
             if (m0 != 0ull && m1 != 0ull) {
                 // both needed by someone: majority vote on which is nearer
                 const unsigned long long c = __builtin_amdgcn_ballot_w64(k0 <= k1);
@@ -259,9 +260,9 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
                                                sdfgpu_stats* st) {
     // wave-reduce the per-lane counters, one atomic per counter per wave
-    uint32_t v[6] = {wc.lane_queries, wc.lane_inner, wc.lane_sphere, wc.lane_box, steps, rays};
+    uint32_t v[7] = {wc.lane_queries, wc.lane_inner, wc.lane_sphere, wc.lane_box, steps, rays, wc.lane_needed};
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
     if (lane == 0) {
         atomicAdd((unsigned long long*)&st->queries, (unsigned long long)v[0]);
@@ -270,6 +271,7 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
         atomicAdd((unsigned long long*)&st->box_evals, (unsigned long long)v[3]);
         atomicAdd((unsigned long long*)&st->steps, (unsigned long long)v[4]);
         atomicAdd((unsigned long long*)&st->rays, (unsigned long long)v[5]);
+        atomicAdd((unsigned long long*)&st->inner_needed, (unsigned long long)v[6]);
         atomicAdd((unsigned long long*)&st->wave_inner, (unsigned long long)wc.wave_inner);
         atomicAdd((unsigned long long*)&st->wave_leaf, (unsigned long long)wc.wave_leaf);
         atomicAdd((unsigned long long*)&st->wave_steps, (unsigned long long)wc.wave_steps);
