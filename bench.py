@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none"])
     ap.add_argument("--skip-ext", type=float, default=0.0, help="SDFGPU_OPT_SKIP_EXTENSION (<0: half the mean primitive size)")
     ap.add_argument("--compaction", action="store_true", help="multi-pass march with ray compaction (SDFGPU_OPT_COMPACTION=1)")
+    ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (1 = strictly one after the other)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
     ap.add_argument("--knn-points", type=int, default=10_000_000)
@@ -178,54 +179,81 @@ def main():
 
     npix = w * h
     tiles = P.n_tiles(w, h)
-    stream = torch.cuda.current_stream().cuda_stream
-    o_hit = torch.empty(npix, dtype=torch.uint8, device=dev)
-    o_depth = torch.empty(npix, dtype=torch.float32, device=dev)
-    o_normal = torch.empty(npix * 3, dtype=torch.float32, device=dev)
-    o_prim = torch.empty(npix, dtype=torch.int32, device=dev)
+    # Frame pipelining: consecutive frames alternate between `depth` slots, each with its own
+    # stream and output buffers, so the drain of one frame (a few long grazing rays on a mostly
+    # idle GPU) overlaps the start of the next.  Frames are independent; each is complete
+    # (march + normals [+ gather + assembly]) before its slot is reused.
+    depth = max(1, a.pipeline)
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(depth - 1)]
+
+    class Slot:
+        pass
+
+    slots = []
+    for sidx in range(depth):
+        sl = Slot()
+        sl.stream = streams[sidx]
+        sl.o_hit = torch.empty(npix, dtype=torch.uint8, device=dev)
+        sl.o_depth = torch.empty(npix, dtype=torch.float32, device=dev)
+        sl.o_normal = torch.empty(npix * 3, dtype=torch.float32, device=dev)
+        sl.o_prim = torch.empty(npix, dtype=torch.int32, device=dev)
+        if world > 1:
+            nbytes = P.packed_bytes(world, tiles)
+            # one packed byte buffer per rank: [depth f32 | normal 3xf32 | prim u32 | hit u8]
+            sl.mine = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            sl.gathered = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+        slots.append(sl)
+    o_hit = slots[0].o_hit
+    torch.cuda.synchronize()
 
     if world == 1:
-        def step():
-            gpu.render_dev(cam, w, h, mp, o_hit.data_ptr(), o_depth.data_ptr(), o_normal.data_ptr(),
-                           o_prim.data_ptr(), stream)
+        def step(k=0):
+            sl = slots[k % depth]
+            gpu.render_dev(cam, w, h, mp, sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(),
+                           sl.o_prim.data_ptr(), sl.stream.cuda_stream)
     else:
         first, stride, cnt = P.rank_tiles(rank, world, tiles)
         nbytes = P.packed_bytes(world, tiles)
-        # one packed byte buffer per rank: [depth f32 | normal 3xf32 | prim u32 | hit u8]
-        mine = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
-        m_hit, m_depth, m_normal, m_prim = P.planes(mine, world, tiles)
 
-        def step():
-            gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, m_hit.data_ptr(), m_depth.data_ptr(),
-                                 m_normal.data_ptr(), m_prim.data_ptr(), stream)
-            dist.all_gather_into_tensor(gathered, mine)
-            if rank == 0:
-                for r in range(world):
-                    g_hit, g_depth, g_normal, g_prim = P.planes(gathered[r * nbytes: (r + 1) * nbytes], world, tiles)
-                    rf, rs, rc = P.rank_tiles(r, world, tiles)
-                    gpu.untile_dev(w, h, rf, rs, rc, g_hit.data_ptr(), g_depth.data_ptr(),
-                                   g_normal.data_ptr(), g_prim.data_ptr(), o_hit.data_ptr(), o_depth.data_ptr(),
-                                   o_normal.data_ptr(), o_prim.data_ptr(), stream)
+        def step(k=0):
+            sl = slots[k % depth]
+            with torch.cuda.stream(sl.stream):
+                m_hit, m_depth, m_normal, m_prim = P.planes(sl.mine, world, tiles)
+                gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, m_hit.data_ptr(), m_depth.data_ptr(),
+                                     m_normal.data_ptr(), m_prim.data_ptr(), sl.stream.cuda_stream)
+                dist.all_gather_into_tensor(sl.gathered, sl.mine)
+                if rank == 0:
+                    for r in range(world):
+                        g_hit, g_depth, g_normal, g_prim = P.planes(sl.gathered[r * nbytes: (r + 1) * nbytes], world, tiles)
+                        rf, rs, rc = P.rank_tiles(r, world, tiles)
+                        gpu.untile_dev(w, h, rf, rs, rc, g_hit.data_ptr(), g_depth.data_ptr(),
+                                       g_normal.data_ptr(), g_prim.data_ptr(), sl.o_hit.data_ptr(), sl.o_depth.data_ptr(),
+                                       sl.o_normal.data_ptr(), sl.o_prim.data_ptr(), sl.stream.cuda_stream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for k in range(a.warmup):
+        step(k)
     barrier()
-    # kernel-only durations of the dominant kernel, HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # Duration of the dominant kernel when it has the GPU to itself (roofline): HIP events
+    # around single launches on the launch stream, outside the timed region.
+    kms = []
+    if world == 1:
+        for _ in range(min(10, max(3, a.steps))):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main_stream)
+            step(0)
+            e1.record(main_stream)
+            torch.cuda.synchronize()
+            kms.append(e0.elapsed_time(e1))
+    barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        if world == 1:
-            ev[k][0].record()
-            step()
-            ev[k][1].record()
-        else:
-            step()
+        step(k)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -259,12 +287,12 @@ def main():
                 "tree_bytes_hbm": int(info.device_bytes),
                 "max_steps": int(mp.max_steps), "eps_hit": float(mp.eps_hit), "t_max": float(mp.t_max),
                 "normal_h": float(mp.normal_h),
+                "frames_in_flight": depth,
                 "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL all-gather",
                 "hit_fraction": hit_frac,
             },
         }
         if world == 1:
-            kms = [s.elapsed_time(e) for s, e in ev]
             k_avg = float(np.mean(kms))
             st = gpu.render_stats(cam, w, h, mp)
             flops = W.algorithmic_flops(st)
