@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE config (2, 3 or 4 are frames)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none"])
+    ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none", "bvh"])
     ap.add_argument("--skip-ext", type=float, default=0.0, help="SDFGPU_OPT_SKIP_EXTENSION (<0: half the mean primitive size)")
     ap.add_argument("--compaction", action="store_true", help="multi-pass march with ray compaction (SDFGPU_OPT_COMPACTION=1)")
     ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (1 = strictly one after the other)")
@@ -171,7 +171,7 @@ def main():
     w, h = a.width or wl.width, a.height or wl.height
     buf = W.scene(wl)
     cam, mp = W.camera(wl, w, h), W.march(wl)
-    bounds = {"auto": S.BOUNDS_AUTO, "aabb": S.BOUNDS_AABB, "obb": S.BOUNDS_OBB, "none": S.BOUNDS_NONE}[a.bounds]
+    bounds = {"auto": S.BOUNDS_AUTO, "aabb": S.BOUNDS_AABB, "obb": S.BOUNDS_OBB, "none": S.BOUNDS_NONE, "bvh": S.BOUNDS_BVH}[a.bounds]
     gpu = S.SdfGpu(local_rank)
     info = gpu.upload_tree(buf, bounds=bounds)
     gpu.set_skip_extension(a.skip_ext)
@@ -283,7 +283,7 @@ def main():
                 "workload": wl.name,
                 "width": w, "height": h, "n_prims": wl.n_prims, "seed": hex(wl.seed),
                 "tree_nodes": int(info.n_nodes), "tree_levels": int(info.max_level),
-                "bounds": {1: "aabb", 2: "obb", 3: "none"}[int(info.bounds)],
+                "bounds": {1: "aabb", 2: "obb", 3: "none", 4: "bvh"}[int(info.bounds)],
                 "tree_bytes_hbm": int(info.device_bytes),
                 "max_steps": int(mp.max_steps), "eps_hit": float(mp.eps_hit), "t_max": float(mp.t_max),
                 "normal_h": float(mp.normal_h),

@@ -6,7 +6,7 @@ include/sdfgpu.h (gpu.py).  Importing the package loads libsdfgpu.so and fails
 loudly if it has not been built.
 """
 from . import _ffi
-from ._ffi import (BOUNDS_AABB, BOUNDS_AUTO, BOUNDS_NONE, BOUNDS_OBB, NO_PRIM,
+from ._ffi import (BOUNDS_AABB, BOUNDS_AUTO, BOUNDS_BVH, BOUNDS_NONE, BOUNDS_OBB, NO_PRIM,
                    Camera, MarchParams, load_library)
 from .gpu import SdfGpu, SdfGpuError, camera_look_at, compact_host, march_params
 from .scene import (ExpandedSdfNode, Quat, SdfBox, SdfBuilder, SdfError, SdfNode,

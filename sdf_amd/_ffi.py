@@ -48,7 +48,7 @@ assert DT_DTYPE.itemsize == 624 and UT_DTYPE.itemsize == 224
 PRIM_SPHERE, PRIM_BOX, OP_UNION, OP_CAA_CLONE = 0, 2, 0, 1
 NO_PRIM = 0xFFFFFFFF
 
-BOUNDS_AUTO, BOUNDS_AABB, BOUNDS_OBB, BOUNDS_NONE = 0, 1, 2, 3
+BOUNDS_AUTO, BOUNDS_AABB, BOUNDS_OBB, BOUNDS_NONE, BOUNDS_BVH = 0, 1, 2, 3, 4
 LAYOUT_GLAM_SSE2 = 0
 
 OK = 0

@@ -160,6 +160,96 @@ uint32_t emit(Ctx& c, uint32_t i, Box3* box, uint32_t* depth) {
     return self;
 }
 
+// ---- BVH mode: the library's own hierarchy over the primitives -------------
+// Binned surface-area-heuristic build (16 bins per axis) over the primitives'
+// world AABBs.  The buffer's topology is not used at all here: the result of a
+// query is the minimum over ALL primitives under an order-independent tie rule,
+// so any hierarchy over the same leaves returns the same (distance, index).
+struct PrimBox {
+    Box3 b;
+    double c[3];
+    uint32_t id;
+};
+
+double half_area(const Box3& b) {
+    double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+void grow(Box3& a, const Box3& b) {
+    for (int k = 0; k < 3; ++k) { a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]); }
+}
+Box3 empty_box() { return Box3{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}; }
+
+uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, CompactTree& out, Box3* box, uint32_t* depth) {
+    if (hi - lo == 1) {
+        *box = p[lo].b;
+        *depth = 0;
+        return REF_LEAF | p[lo].id;
+    }
+    constexpr int NB = 16;
+    double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = lo; i < hi; ++i)
+        for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], p[i].c[a]); cmax[a] = std::max(cmax[a], p[i].c[a]); }
+    int best_axis = -1, best_bin = 0;
+    double best_cost = INFINITY;
+    for (int a = 0; a < 3; ++a) {
+        const double ext = cmax[a] - cmin[a];
+        if (!(ext > 0.0)) continue;
+        Box3 bb[NB];
+        uint32_t cnt[NB] = {0};
+        for (auto& b : bb) b = empty_box();
+        const double sc = NB / ext;
+        for (uint32_t i = lo; i < hi; ++i) {
+            int k = std::min(NB - 1, (int)((p[i].c[a] - cmin[a]) * sc));
+            cnt[k]++;
+            grow(bb[k], p[i].b);
+        }
+        double ra[NB];
+        uint32_t rn[NB];
+        Box3 acc = empty_box();
+        uint32_t n = 0;
+        for (int k = NB - 1; k > 0; --k) { grow(acc, bb[k]); n += cnt[k]; ra[k] = n ? half_area(acc) : 0.0; rn[k] = n; }
+        acc = empty_box();
+        n = 0;
+        for (int k = 0; k < NB - 1; ++k) {
+            grow(acc, bb[k]);
+            n += cnt[k];
+            if (n == 0 || rn[k + 1] == 0) continue;
+            const double cost = half_area(acc) * n + ra[k + 1] * rn[k + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+        }
+    }
+    uint32_t mid;
+    if (best_axis < 0) {
+        mid = (lo + hi) / 2;   // coincident centres: split by position in the array
+    } else {
+        const double ext = cmax[best_axis] - cmin[best_axis], sc = NB / ext;
+        auto it = std::partition(p.begin() + lo, p.begin() + hi, [&](const PrimBox& q) {
+            return std::min(NB - 1, (int)((q.c[best_axis] - cmin[best_axis]) * sc)) <= best_bin;
+        });
+        mid = (uint32_t)(it - p.begin());
+        if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+    }
+    const uint32_t self = (uint32_t)out.inner.size();
+    out.inner.emplace_back();
+    Box3 b0{}, b1{};
+    uint32_t d0 = 0, d1 = 0;
+    const uint32_t r0 = build_sah(p, lo, mid, out, &b0, &d0);
+    const uint32_t r1 = build_sah(p, mid, hi, out, &b1, &d1);
+    GpuInner& g = out.inner[self];
+    std::memset(&g, 0, sizeof g);
+    for (int a = 0; a < 3; ++a) {
+        g.lo0[a] = round_down(b0.lo[a]); g.hi0[a] = round_up(b0.hi[a]);
+        g.lo1[a] = round_down(b1.lo[a]); g.hi1[a] = round_up(b1.hi[a]);
+        box->lo[a] = std::min(b0.lo[a], b1.lo[a]);
+        box->hi[a] = std::max(b0.hi[a], b1.hi[a]);
+    }
+    g.ref0 = r0;
+    g.ref1 = r1;
+    *depth = 1 + std::max(d0, d1);
+    return self;
+}
+
 int fail(std::string* err, int code, const char* fmt, uint32_t a = 0, uint32_t b = 0) {
     if (err) {
         char buf[256];
@@ -176,10 +266,10 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     *out = CompactTree();
     if (layout != SDFGPU_LAYOUT_GLAM_SSE2)
         return fail(err, SDFGPU_ERR_LAYOUT, "unsupported record layout %u (only glam SSE2: 624/224-byte records)", layout);
-    if (bounds > SDFGPU_BOUNDS_NONE) return fail(err, SDFGPU_ERR_INVALID_ARG, "unknown bounds mode %u", bounds);
+    if (bounds > SDFGPU_BOUNDS_BVH) return fail(err, SDFGPU_ERR_INVALID_ARG, "unknown bounds mode %u", bounds);
     out->info.n_nodes = n;
     if (n == 0) {  // faux_shader.rs:104,207: empty buffer -> +inf
-        out->info.bounds = bounds == SDFGPU_BOUNDS_AUTO ? (uint32_t)SDFGPU_BOUNDS_AABB : bounds;
+        out->info.bounds = bounds == SDFGPU_BOUNDS_AUTO ? (uint32_t)SDFGPU_BOUNDS_BVH : bounds;
         out->info.identity_inner = 1;
         out->info.rigid_leaves = 1;
         return SDFGPU_OK;
@@ -280,7 +370,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
 
     if (!identity_inner || !exact_rows) {
         // General path: no pruning, the literal per-level point chain.
-        if (bounds == SDFGPU_BOUNDS_AABB || bounds == SDFGPU_BOUNDS_OBB)
+        if (bounds == SDFGPU_BOUNDS_AABB || bounds == SDFGPU_BOUNDS_OBB || bounds == SDFGPU_BOUNDS_BVH)
             return fail(err, SDFGPU_ERR_BAD_TREE,
                         "pruned bounds need identity internal trans_inverse and affine leaf rows; use AUTO or NONE");
         if (max_level > GEN_MAX_LEVELS)
@@ -313,8 +403,8 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     }
 
     uint32_t mode = bounds;
-    if (mode == SDFGPU_BOUNDS_AUTO) mode = rigid ? SDFGPU_BOUNDS_AABB : SDFGPU_BOUNDS_NONE;
-    if (mode == SDFGPU_BOUNDS_AABB && !rigid)
+    if (mode == SDFGPU_BOUNDS_AUTO) mode = rigid ? SDFGPU_BOUNDS_BVH : SDFGPU_BOUNDS_NONE;
+    if ((mode == SDFGPU_BOUNDS_AABB || mode == SDFGPU_BOUNDS_BVH) && !rigid)
         return fail(err, SDFGPU_ERR_BAD_TREE, "AABB bounds need rigid leaf transforms (trans_inverse is not orthonormal)");
     if (mode == SDFGPU_BOUNDS_OBB) {
         for (uint32_t i = 0; i < n; ++i) {
@@ -352,7 +442,20 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     else out->inner.reserve(n_inner);
     Box3 root{};
     uint32_t depth = 0;
-    out->root_ref = emit(c, 0, &root, &depth);
+    if (mode == SDFGPU_BOUNDS_BVH) {
+        std::vector<PrimBox> prims(n_prims);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!dt[i].is_primitive) continue;
+            PrimBox& q = prims[c.prim_id[i]];
+            q.id = c.prim_id[i];
+            if (!leaf_aabb(dt[i], &q.b)) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u: singular transform", i);
+            for (int a = 0; a < 3; ++a) q.c[a] = 0.5 * (q.b.lo[a] + q.b.hi[a]);
+        }
+        out->root_ref = build_sah(prims, 0, n_prims, *out, &root, &depth);
+        if (depth > 64) return fail(err, SDFGPU_ERR_TOO_DEEP, "built hierarchy is %u levels deep (limit 64)", depth);
+    } else {
+        out->root_ref = emit(c, 0, &root, &depth);
+    }
     out->stack_depth = std::max(1u, depth);
     out->margin_T = margin_T;
 

@@ -24,14 +24,14 @@ def test_accepts_well_formed_trees_and_reports_info():
         rc, info, msg = S.compact_host(buf)
         assert rc == 0, msg
         assert (info.n_nodes, info.n_prims) == (2 * n - 1, n)
-        assert info.bounds == S.BOUNDS_AABB and info.identity_inner == 1 and info.rigid_leaves == 1
+        assert info.bounds == S.BOUNDS_BVH and info.identity_inner == 1 and info.rigid_leaves == 1
         assert info.max_level == int(np.ceil(np.log2(n))) + 1 if n > 1 else info.max_level == 1
         assert info.device_bytes == 64 * (n + info.n_inner)
     rc, info, _ = S.compact_host(S.SdfTreeBuffer.make_empty())
     assert rc == 0 and info.n_nodes == 0
 
 
-@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE])
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE, S.BOUNDS_BVH])
 def test_every_bounds_mode_compacts(bounds):
     rc, info, msg = S.compact_host(good(50, 2), bounds=bounds)
     assert rc == 0 and info.bounds == bounds, msg

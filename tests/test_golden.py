@@ -38,7 +38,7 @@ def test_oracle_reproduces_golden(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bounds", [1, 2, 3], ids=["aabb", "obb", "none"])
+@pytest.mark.parametrize("bounds", [1, 2, 3, 4], ids=["aabb", "obb", "none", "bvh"])
 @pytest.mark.parametrize("path", GOLDEN, ids=IDS)
 def test_gpu_reproduces_golden(gpu, path, bounds):
     z, buf, cam, mp = load(path)

@@ -10,7 +10,7 @@ from conftest import bits, make_points
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE])
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE, S.BOUNDS_BVH])
 @pytest.mark.parametrize("n,k", [(1, 8), (3, 8), (5, 3), (64, 1), (200, 8), (200, 16), (1000, 8)])
 def test_knn_matches_oracle(gpu, n, k, bounds):
     buf = S.random_scene_buffer(n, 0x4B00 + n)

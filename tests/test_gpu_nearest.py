@@ -22,7 +22,7 @@ def _check(gpu, buf, pts, bounds, mode=O.MODE_EXHAUSTIVE):
     assert np.array_equal(i, i0), f"indices differ at {np.flatnonzero(i != i0)[:8]}"
 
 
-@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE])
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE, S.BOUNDS_BVH])
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 257, 1000])
 def test_nearest_matches_oracle(gpu, n, bounds):
     buf = S.random_scene_buffer(n, 0x5DF00000 + n)

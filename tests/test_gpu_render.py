@@ -29,7 +29,7 @@ def _compare(img, ref):
     assert np.array_equal(bits(img["normal"]), bits(ref["normal"]))
 
 
-@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB])
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_BVH])
 @pytest.mark.parametrize("n,w,h", [(1, 64, 48), (7, 64, 48), (64, 96, 64), (1000, 160, 96)])
 def test_render_matches_oracle(gpu, n, w, h, bounds):
     buf = S.random_scene_buffer(n, 0x5DF00100 + n)
