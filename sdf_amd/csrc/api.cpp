@@ -34,7 +34,10 @@ struct sdfgpu_ctx {
     // Morton reordering of query batches (sort.hip)
     DevBuf keys_a, keys_b, idx_a, idx_b, sort_tmp;
     // multi-pass march (ray compaction)
-    DevBuf march;
+    // one scratch per stream that has rendered: frames in flight on different streams
+    // must not share pass state
+    struct MarchScratch { hipStream_t stream; DevBuf buf; };
+    std::vector<MarchScratch> march;
     bool compaction = false;
     std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
     bool reorder = true;
@@ -139,7 +142,8 @@ std::vector<uint32_t> default_pass_steps() {
     return {12, 20, 28, 40, 56, 80};
 }
 
-int march_setup(sdfgpu_ctx* c, uint32_t tile_count, uint32_t max_steps, RenderScratch* rs, std::vector<uint32_t>* bounds) {
+int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t max_steps, RenderScratch* rs,
+                std::vector<uint32_t>* bounds) {
     bounds->clear();
     bounds->push_back(0);
     if (c->compaction)
@@ -149,9 +153,18 @@ int march_setup(sdfgpu_ctx* c, uint32_t tile_count, uint32_t max_steps, RenderSc
     if (bounds->size() == 2 && (*bounds)[1] == 0) (*bounds)[1] = 0;   // zero steps: one empty pass
     size_t sb = 0, cb = 0;
     const size_t total = render_scratch_bytes(tile_count, &sb, &cb);
-    int rc = reserve(c, c->march, total);
+    if (bounds->size() == 2) return SDFGPU_OK;   // single pass: no pass state
+    DevBuf* mb = nullptr;
+    for (auto& m : c->march)
+        if (m.stream == stream) mb = &m.buf;
+    if (!mb) {
+        if (c->march.size() >= 16) return set_err(c, SDFGPU_ERR_TOO_LARGE, "compaction: more than 16 distinct streams on one context");
+        c->march.push_back({stream, DevBuf()});
+        mb = &c->march.back().buf;
+    }
+    int rc = reserve(c, *mb, total);
     if (rc) return rc;
-    char* base = (char*)c->march.p;
+    char* base = (char*)mb->p;
     rs->state[0] = base;
     rs->state[1] = base + sb;
     rs->counts = (uint32_t*)(base + 2 * sb);
@@ -215,8 +228,10 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     free_tree(c);
     for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats, &c->keys_a, &c->keys_b, &c->idx_a,
-                      &c->idx_b, &c->sort_tmp, &c->march})
+                      &c->idx_b, &c->sort_tmp})
         if (b->p) (void)hipFree(b->p);
+    for (auto& m : c->march)
+        if (m.buf.p) (void)hipFree(m.buf.p);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -259,6 +274,7 @@ int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOper
     if ((rc = upload_vec(c, t.gen, &c->tree.gen)) != SDFGPU_OK) return rc;
     c->tree.n_gen = (uint32_t)t.gen.size();
     c->tree.root_ref = t.root_ref;
+    c->tree.n_leaf = (uint32_t)t.leaves.size();
     c->tree.stack_depth = t.stack_depth;
     c->tree.bounds = t.info.bounds;
     c->tree.margin_T = t.margin_T;
@@ -414,7 +430,7 @@ int sdfgpu_render_tiles_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w,
         return set_err(c, SDFGPU_ERR_INVALID_ARG, "tile range outside the frame");
     RenderScratch rs;
     std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, tile_count, mp->max_steps, &rs, &pb))) return rc;
+    if ((rc = march_setup(c, (hipStream_t)stream, tile_count, mp->max_steps, &rs, &pb))) return rc;
     HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, tile_first, tile_stride, tile_count, false, rs, pb.data(),
                              (uint32_t)pb.size(), d_hit, d_depth, d_normal, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
@@ -429,7 +445,7 @@ int sdfgpu_render_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint3
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
     RenderScratch rs;
     std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, tiles, mp->max_steps, &rs, &pb))) return rc;
+    if ((rc = march_setup(c, (hipStream_t)stream, tiles, mp->max_steps, &rs, &pb))) return rc;
     HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(), d_hit,
                              d_depth, d_normal, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
@@ -466,7 +482,7 @@ int sdfgpu_render(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t 
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
     RenderScratch rs;
     std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, tiles, mp->max_steps, &rs, &pb))) return rc;
+    if ((rc = march_setup(c, c->stream, tiles, mp->max_steps, &rs, &pb))) return rc;
     HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(),
                              (uint8_t*)c->out_a.p, (float*)c->out_b.p, (float*)c->out_c.p, (uint32_t*)c->out_d.p, nullptr,
                              c->stream));
@@ -490,7 +506,7 @@ int sdfgpu_render_stats(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uin
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
     RenderScratch rs;
     std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, tiles, mp->max_steps, &rs, &pb))) return rc;
+    if ((rc = march_setup(c, c->stream, tiles, mp->max_steps, &rs, &pb))) return rc;
     HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(),
                              (uint8_t*)c->out_a.p, nullptr, nullptr, nullptr, (sdfgpu_stats*)c->stats.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));

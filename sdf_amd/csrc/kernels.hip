@@ -102,6 +102,7 @@ struct TreeView {
     const GpuInnerObb* __restrict__ inner_obb;
     uint32_t root;
     uint32_t depth;     // LDS stack levels per wave
+    uint32_t n_leaf;
     float margin_T;
     float skip_ext;     // widening of the search radius that pays for skipped walks (render)
 };
@@ -427,8 +428,12 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         slot = wave_id * 64u + lane;
         alive = true;
     } else {
-        const uint32_t n_src = pa.in_hdr[0], total = pa.in_hdr[1];
-        if (wave_id * 64u >= total) return;
+        // header / offsets are clamped to what the scratch can hold, so that even
+        // corrupted pass state (two frames sharing one scratch) cannot index outside it
+        uint32_t n_src = pa.in_hdr[0], total = pa.in_hdr[1];
+        n_src = n_src < tile_count ? n_src : tile_count;
+        total = total < tile_count * 64u ? total : tile_count * 64u;
+        if (n_src == 0u || wave_id * 64u >= total) return;
         const uint32_t j = wave_id * 64u + lane;
         alive = j < total;
         if (alive) {
@@ -438,8 +443,15 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
                 const uint32_t mid = (lo + hi) >> 1;
                 if (pa.in_offsets[mid] <= j) lo = mid; else hi = mid;
             }
-            const RayState rs = pa.in_state[(size_t)lo * 64u + (j - pa.in_offsets[lo])];
-            t = rs.t; budget = rs.budget; last = rs.last; slot = rs.slot;
+            const uint32_t rank = j - pa.in_offsets[lo];
+            if (rank < 64u) {
+                const RayState rs = pa.in_state[(size_t)lo * 64u + rank];
+                t = rs.t; budget = rs.budget; last = rs.last;
+                slot = rs.slot < tile_count * 64u ? rs.slot : 0u;
+                if (last != SDF_NO_PRIM && last >= T.n_leaf) last = SDF_NO_PRIM;
+            } else {
+                alive = false;
+            }
         }
     }
     const uint32_t tile_local = slot >> 6, pl = slot & 63u;
@@ -575,7 +587,8 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ prev_hdr,
                                                            uint32_t* __restrict__ offsets, uint32_t* __restrict__ hdr) {
     __shared__ uint32_t part[1024];
-    const uint32_t n = prev_hdr ? (prev_hdr[1] + 63u) / 64u : n_first;
+    uint32_t n = prev_hdr ? (prev_hdr[1] + 63u) / 64u : n_first;
+    n = n < n_first ? n : n_first;   // never beyond the scratch (n_first = tile_count)
     const uint32_t tid = threadIdx.x;
     const uint32_t chunk = (n + 1023u) / 1024u;
     const uint32_t lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -803,6 +816,7 @@ static TreeView make_view(const DeviceTree& d) {
     v.root = d.root_ref;
     v.depth = d.stack_depth;
     v.margin_T = d.margin_T;
+    v.n_leaf = d.n_leaf;
     v.skip_ext = d.skip_ext;
     return v;
 }

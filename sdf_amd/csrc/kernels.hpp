@@ -16,6 +16,7 @@ struct DeviceTree {
     GpuGenNode* gen = nullptr;          // general path: all nodes, pre-order
     uint32_t n_gen = 0;
     uint32_t root_ref = REF_NONE;
+    uint32_t n_leaf = 0;
     uint32_t stack_depth = 1;
     uint32_t bounds = SDFGPU_BOUNDS_AABB;
     float margin_T = 0.f;

@@ -155,4 +155,50 @@ def test_ray_compaction_is_invisible(gpu, max_steps):
     for on in (True, False):
         gpu.set_compaction(on)
         _compare(gpu.render(cam, w, h, mp), ref)
+    gpu.set_compaction(False)
+
+
+def test_compaction_two_frames_in_flight(gpu):
+    # two frames on two streams of one context, compaction on: each stream owns its
+    # pass state, so both frames equal the single-stream frame bit for bit
+    import torch
+
+    n, w, h = 400, 320, 200
+    buf = S.random_scene_buffer(n, 0xF00D)
+    L = S.default_extent(n)
+    cams = [
+        S.camera_look_at((0.2 * L, 0.1 * L, -1.2 * L), (0, 0, 0), (0, 1, 0), 1.0, w, h),
+        S.camera_look_at((-0.9 * L, 0.4 * L, 0.8 * L), (0, 0, 0), (0, 1, 0), 0.8, w, h),
+    ]
+    mp = S.march_params(max_steps=96, eps_hit=1e-3, t_min=0.0, t_max=6 * L, normal_h=1e-4)
+    gpu.upload_tree(buf)
+    gpu.set_compaction(False)
+    want = [gpu.render(c, w, h, mp) for c in cams]
     gpu.set_compaction(True)
+    try:
+        dev = torch.device("cuda:0")
+        streams = [torch.cuda.Stream(dev) for _ in cams]
+        outs = []
+        for _ in cams:
+            outs.append((
+                torch.empty(w * h, dtype=torch.uint8, device=dev),
+                torch.empty(w * h, dtype=torch.float32, device=dev),
+                torch.empty(w * h * 3, dtype=torch.float32, device=dev),
+                torch.empty(w * h, dtype=torch.int32, device=dev),
+            ))
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for cam, st, o in zip(cams, streams, outs):
+                gpu.render_dev(cam, w, h, mp, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                               stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for o, ref in zip(outs, want):
+            got = {
+                "hit": o[0].cpu().numpy(),
+                "depth": o[1].cpu().numpy(),
+                "normal": o[2].cpu().numpy().reshape(-1, 3),
+                "prim": o[3].cpu().numpy().view(np.uint32),
+            }
+            _compare(got, ref)
+    finally:
+        gpu.set_compaction(False)
