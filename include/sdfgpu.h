@@ -73,7 +73,7 @@ typedef struct sdfgpu_tree_info {
     uint32_t bounds;         /* sdfgpu_bounds actually in use */
     uint32_t identity_inner; /* 1 if every internal trans_inverse is exactly I */
     uint32_t rigid_leaves;   /* 1 if every leaf trans_inverse is a rigid motion (tol 1e-4) */
-    uint32_t reserved;
+    uint32_t stack_depth;     /* levels of the resident hierarchy = entries of the per-wavefront stack */
     uint64_t device_bytes;   /* compact tree bytes resident in HBM */
     float scene_lo[3];       /* root AABB (AABB mode) */
     float scene_hi[3];

@@ -67,7 +67,7 @@ class TreeInfo(C.Structure):
         ("bounds", C.c_uint32),
         ("identity_inner", C.c_uint32),
         ("rigid_leaves", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("stack_depth", C.c_uint32),
         ("device_bytes", C.c_uint64),
         ("scene_lo", C.c_float * 3),
         ("scene_hi", C.c_float * 3),

@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace sdfgpu {
@@ -180,13 +181,18 @@ void grow(Box3& a, const Box3& b) {
 }
 Box3 empty_box() { return Box3{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}; }
 
-uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, CompactTree& out, Box3* box, uint32_t* depth) {
+// `budget` = inner levels this subtree may still use (the per-wave stack of the kernels and
+// their LDS footprint are sized by it): a split is only eligible when both sides still fit a
+// balanced tree of budget-1 levels; when no SAH candidate does, the set is halved at the median.
+uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, uint32_t budget, CompactTree& out, Box3* box,
+                   uint32_t* depth) {
     if (hi - lo == 1) {
         *box = p[lo].b;
         *depth = 0;
         return REF_LEAF | p[lo].id;
     }
     constexpr int NB = 16;
+    const uint64_t cap = budget - 1 >= 32 ? (1ull << 32) : (1ull << (budget - 1));   // budget >= 1 here
     double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = lo; i < hi; ++i)
         for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], p[i].c[a]); cmax[a] = std::max(cmax[a], p[i].c[a]); }
@@ -214,14 +220,22 @@ uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, CompactTre
         for (int k = 0; k < NB - 1; ++k) {
             grow(acc, bb[k]);
             n += cnt[k];
-            if (n == 0 || rn[k + 1] == 0) continue;
+            if (n == 0 || rn[k + 1] == 0 || n > cap || rn[k + 1] > cap) continue;
             const double cost = half_area(acc) * n + ra[k + 1] * rn[k + 1];
             if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
         }
     }
     uint32_t mid;
     if (best_axis < 0) {
-        mid = (lo + hi) / 2;   // coincident centres: split by position in the array
+        // coincident centres, or no eligible SAH split: halve at the median of the widest axis
+        mid = (lo + hi) / 2;
+        int wa = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cmax[a] - cmin[a] > cmax[wa] - cmin[wa]) wa = a;
+        if (cmax[wa] - cmin[wa] > 0.0)
+            std::nth_element(p.begin() + lo, p.begin() + mid, p.begin() + hi, [wa](const PrimBox& x, const PrimBox& y) {
+                return x.c[wa] < y.c[wa] || (x.c[wa] == y.c[wa] && x.id < y.id);
+            });
     } else {
         const double ext = cmax[best_axis] - cmin[best_axis], sc = NB / ext;
         auto it = std::partition(p.begin() + lo, p.begin() + hi, [&](const PrimBox& q) {
@@ -234,8 +248,8 @@ uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, CompactTre
     out.inner.emplace_back();
     Box3 b0{}, b1{};
     uint32_t d0 = 0, d1 = 0;
-    const uint32_t r0 = build_sah(p, lo, mid, out, &b0, &d0);
-    const uint32_t r1 = build_sah(p, mid, hi, out, &b1, &d1);
+    const uint32_t r0 = build_sah(p, lo, mid, budget - 1, out, &b0, &d0);
+    const uint32_t r1 = build_sah(p, mid, hi, budget - 1, out, &b1, &d1);
     GpuInner& g = out.inner[self];
     std::memset(&g, 0, sizeof g);
     for (int a = 0; a < 3; ++a) {
@@ -451,8 +465,14 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             if (!leaf_aabb(dt[i], &q.b)) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u: singular transform", i);
             for (int a = 0; a < 3; ++a) q.c[a] = 0.5 * (q.b.lo[a] + q.b.hi[a]);
         }
-        out->root_ref = build_sah(prims, 0, n_prims, *out, &root, &depth);
-        if (depth > 64) return fail(err, SDFGPU_ERR_TOO_DEEP, "built hierarchy is %u levels deep (limit 64)", depth);
+        // depth budget: balanced depth + slack, never beyond the 64-entry wave stack
+        uint32_t lg = 0;
+        while ((1ull << lg) < n_prims) ++lg;
+        uint32_t slack = 8;
+        if (const char* e = std::getenv("SDFGPU_BVH_SLACK")) slack = (uint32_t)std::max(0, std::atoi(e));
+        const uint32_t budget = std::min(64u, std::max(1u, lg + slack));
+        out->root_ref = build_sah(prims, 0, n_prims, budget, *out, &root, &depth);
+        if (depth > budget) return fail(err, SDFGPU_ERR_TOO_DEEP, "built hierarchy is %u levels deep (budget %u)", depth, budget);
     } else {
         out->root_ref = emit(c, 0, &root, &depth);
     }
@@ -463,6 +483,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     info.n_prims = n_prims;
     info.n_inner = (uint32_t)(mode == SDFGPU_BOUNDS_OBB ? out->inner_obb.size() : out->inner.size());
     info.max_level = max_level;
+    info.stack_depth = out->stack_depth;
     info.bounds = mode;
     info.identity_inner = identity_inner ? 1 : 0;
     info.rigid_leaves = rigid ? 1 : 0;

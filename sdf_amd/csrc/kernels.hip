@@ -143,6 +143,7 @@ __device__ __forceinline__ bool needed(float key, float thr) {
 
 // K1: the single best under take_better's order.
 struct AccNearest {
+    static constexpr bool TRACKS = false;
     float best;
     uint32_t bid;
     __device__ __forceinline__ float radius() const { return best; }
@@ -154,6 +155,7 @@ struct AccNearest {
 // winner, which let later march steps prove "the same primitive is still the
 // nearest" without walking (valid for every lane, driving or not).
 struct AccTracked {
+    static constexpr bool TRACKS = true;
     float best;
     uint32_t bid;
     float second;   // min computed distance over evaluated primitives other than the winner
@@ -170,92 +172,297 @@ struct AccTracked {
     __device__ __forceinline__ void skipped(float key) { lb_key = min_nn(lb_key, key); }
 };
 
+// One 64-byte record through the scalar cache: a single s_load_dwordx16 at
+// base + (idx << 6) (SGPR offset form: one shift instead of 64-bit pointer
+// arithmetic -- the CU's one scalar unit is the busiest pipe of the walk).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 load_rec64(const void* __restrict__ base, uint32_t idx) {
+    f32x16 r;
+    const uint32_t off = __builtin_amdgcn_readfirstlane(idx << 6);
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(off) : "memory");
+    return r;
+}
+
+// Bits of one float element of such a record as an integer.  A plain bit cast of
+// an extracted element is miscompiled by this toolchain (it reads element 0 of
+// the SGPR tuple), so the reinterpretation is one explicit scalar move.
+__device__ __forceinline__ uint32_t rec_bits(float f) {
+    uint32_t u;
+    asm("s_mov_b32 %0, %1" : "=s"(u) : "s"(f));
+    return u;
+}
+
+__device__ __forceinline__ float leaf_eval_rec(const f32x16& r, float px, float py, float pz) {
+    const float lx = ((r[0] * px + r[1] * py) + r[2] * pz) + r[3];
+    const float ly = ((r[4] * px + r[5] * py) + r[6] * pz) + r[7];
+    const float lz = ((r[8] * px + r[9] * py) + r[10] * pz) + r[11];
+    return prim_value(rec_bits(r[15]), r[12], r[13], r[14], lx, ly, lz);
+}
+
 // Wave-uniform branch-and-prune walk.  On return the accumulator holds the
 // result over every primitive of the tree for each lane whose bit is set in
 // `drive` (other lanes ride along: they see every value the wave evaluates).
 // `stk` = this wave's LDS stack, [depth][64] floats.  All decisions are made
 // on 64-bit lane masks in SGPRs; `ext` widens the search radius (render).
+//
+// Written as an explicit state machine (inner / leaf / pop) with uniform jumps:
+// every branch condition is a scalar, so nothing here needs EXEC masking, and
+// the prune threshold is recomputed only when a leaf changed the radius.
 template <int MODE, bool COUNT, class Acc>
-__device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, unsigned long long drive,
-                                            float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
-                                            WaveCounters& wc) {
+__device__ __forceinline__ void nn_traverse_cxx(const TreeView& T, float px, float py, float pz, unsigned long long drive,
+                                                float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
+                                                WaveCounters& wc) {
     uint32_t cur = T.root;
     if (cur == REF_NONE) return;
     const float mg = prune_margin<MODE>(T, px, py, pz);
     const bool mine = (drive >> lane) & 1ull;
     uint32_t sp = 0;
     int refs = 0;  // lane k holds the reference of stack entry k
+    float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
     if constexpr (COUNT) wc.lane_queries += mine ? 1u : 0u;
-    for (;;) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        bool descend = false;
-        if (cur & REF_LEAF) {
-            const uint32_t id = cur & REF_INDEX;
-            const GpuLeaf* __restrict__ L = T.leaf + id;
-            acc.offer(leaf_eval(L, px, py, pz), id);
-            if constexpr (COUNT) {
-                wc.wave_leaf += 1;
-                if (L->kind == SDF_PRIM_SPHERE) wc.lane_sphere += mine ? 1u : 0u;
-                else wc.lane_box += mine ? 1u : 0u;
-            }
+    cur = __builtin_amdgcn_readfirstlane(cur);
+
+top:   // single loop header (keeps the control flow reducible): cur is a valid reference
+    if (cur & REF_LEAF) goto visit_leaf;
+    {
+        float k0, k1;
+        uint32_t r0, r1;
+        if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
+            const GpuInnerObb* __restrict__ N = T.inner_obb + cur;
+            k0 = obb_mindist(N->fi0, N->sc0, px, py, pz);
+            k1 = obb_mindist(N->fi1, N->sc1, px, py, pz);
+            r0 = N->ref0;
+            r1 = N->ref1;
         } else {
-            float k0, k1;
-            uint32_t r0, r1;
-            if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
-                const GpuInnerObb* __restrict__ N = T.inner_obb + cur;
-                k0 = obb_mindist(N->fi0, N->sc0, px, py, pz);
-                k1 = obb_mindist(N->fi1, N->sc1, px, py, pz);
-                r0 = N->ref0;
-                r1 = N->ref1;
-            } else {
-                const GpuInner* __restrict__ N = T.inner + cur;
-                k0 = aabb_dist2(N->lo0, N->hi0, px, py, pz);
-                k1 = aabb_dist2(N->lo1, N->hi1, px, py, pz);
-                r0 = N->ref0;
-                r1 = N->ref1;
-            }
-            if constexpr (COUNT) {
-                wc.wave_inner += 1;
-                wc.lane_inner += mine ? 1u : 0u;
-            }
-            const float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(needed<MODE>(k0, thr)) & drive;
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(needed<MODE>(k1, thr)) & drive;
-            if constexpr (COUNT) wc.lane_needed += (unsigned)(((m0 | m1) >> lane) & 1ull);
-            if (m0 != 0ull && m1 != 0ull) {
-                // both needed by someone: majority vote on which is nearer
+            const f32x16 N = load_rec64(T.inner, cur);
+            const float lo0[3] = {N[0], N[1], N[2]}, hi0[3] = {N[3], N[4], N[5]};
+            const float lo1[3] = {N[6], N[7], N[8]}, hi1[3] = {N[9], N[10], N[11]};
+            k0 = aabb_dist2(lo0, hi0, px, py, pz);
+            k1 = aabb_dist2(lo1, hi1, px, py, pz);
+            r0 = rec_bits(N[12]);
+            r1 = rec_bits(N[13]);
+        }
+        if constexpr (COUNT) {
+            wc.wave_inner += 1;
+            wc.lane_inner += mine ? 1u : 0u;
+        }
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(needed<MODE>(k0, thr)) & drive;
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(needed<MODE>(k1, thr)) & drive;
+        if constexpr (COUNT) wc.lane_needed += (unsigned)(((m0 | m1) >> lane) & 1ull);
+        if (m0 != 0ull) {
+            if (m1 != 0ull) {
+                // both needed by someone: the lanes that need a child vote for the nearer one
                 const unsigned long long c = __builtin_amdgcn_ballot_w64(k0 <= k1);
                 const uint32_t n0 = (uint32_t)__builtin_popcountll(m0 & (c | ~m1));
-                const uint32_t n1 = (uint32_t)__builtin_popcountll(m1 & (~c | ~m0));
-                const bool first0 = n0 >= n1;
+                const uint32_t nt = (uint32_t)__builtin_popcountll(m0 | m1);
+                const bool first0 = 2u * n0 >= nt;
                 stk[sp * 64u + lane] = first0 ? k1 : k0;
                 refs = (lane == sp) ? (int)(first0 ? r1 : r0) : refs;   // v_writelane has no builtin here
                 sp += 1;
                 cur = first0 ? r0 : r1;
-                descend = true;
             } else {
-                if (m0 == 0ull) acc.skipped(k0);
-                if (m1 == 0ull) acc.skipped(k1);
-                cur = (m0 != 0ull) ? r0 : r1;
-                descend = (m0 | m1) != 0ull;
+                acc.skipped(k1);
+                cur = r0;
             }
+        } else {
+            acc.skipped(k0);
+            if (m1 == 0ull) {
+                acc.skipped(k1);
+                goto pop;
+            }
+            cur = r1;
         }
-        if (!descend) {
-            bool found = false;
-            while (sp != 0) {
-                sp -= 1;
-                const float k = stk[sp * 64u + lane];
-                const float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
-                if ((__builtin_amdgcn_ballot_w64(needed<MODE>(k, thr)) & drive) != 0ull) {
-                    cur = (uint32_t)__builtin_amdgcn_readlane(refs, sp);
-                    found = true;
-                    break;
-                }
-                acc.skipped(k);
-            }
-            if (!found) return;
+        goto top;
+    }
+
+visit_leaf: {
+        const uint32_t id = cur & REF_INDEX;
+        const f32x16 L = load_rec64(T.leaf, id);
+        acc.offer(leaf_eval_rec(L, px, py, pz), id);
+        thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+        if constexpr (COUNT) {
+            wc.wave_leaf += 1;
+            if (rec_bits(L[15]) == SDF_PRIM_SPHERE) wc.lane_sphere += mine ? 1u : 0u;
+            else wc.lane_box += mine ? 1u : 0u;
         }
     }
+
+pop:
+    for (;;) {
+        if (sp == 0) return;
+        sp -= 1;
+        const float k = stk[sp * 64u + lane];
+        if ((__builtin_amdgcn_ballot_w64(needed<MODE>(k, thr)) & drive) != 0ull) break;
+        acc.skipped(k);
+    }
+    cur = (uint32_t)__builtin_amdgcn_readlane(refs, sp);
+    goto top;
+}
+
+// ---- the same walk, inner part hand-scheduled ------------------------------
+// rocprofv3 showed the CU's single scalar unit as the busiest pipe of the
+// compiler's version (~44 SALU per visited node: 64-bit pointer arithmetic,
+// materialised booleans, control-flow glue), so the part of the walk between
+// two primitive evaluations -- descend through internal nodes, push / pop the
+// per-wave stack -- is one block of gfx950 assembly: 1 shift + 1 s_load_dwordx16
+// per node, SCC taken straight from the s_and_b64 that forms the lane mask,
+// ~12 SALU on the two-children path, 3 on the one-child path.  Primitive
+// evaluation (bit-exact arithmetic, accumulators) stays in C++.
+//
+// Contract of the block: on entry `cur` is an internal/leaf reference or
+// REF_POP ("take the next pending subtree"); on exit `cur` is a leaf reference
+// to evaluate, or REF_NONE when the walk is over.  s[80:95] hold the node
+// record.  Hazards: no VALU-written SGPR is read by a VALU here (gfx950 needs
+// two wait states for that); lane masks go VALU->SALU->VALU, which interlocks.
+constexpr uint32_t REF_POP = 0xFFFFFFFEu;
+
+#define SDFGPU_WALK_ASM(LBMIN_K0, LBMIN_K1, LBMIN_A)                                                   \
+    "s_cmp_eq_u32 %[cur], -2\n\t"                                                                      \
+    "s_cbranch_scc1 .Lpop%=\n"                                                                         \
+    ".Ltop%=:\n\t"                                                                                     \
+    "s_bitcmp1_b32 %[cur], 31\n\t"                                                                     \
+    "s_cbranch_scc1 .Ldone%=\n\t"                                                                      \
+    "s_lshl_b32 %[t0], %[cur], 6\n\t"                                                                  \
+    "s_load_dwordx16 s[80:95], %[base], %[t0]\n\t"                                                     \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
+    "v_sub_f32 %[a], s80, %[px]\n\t"                                                                   \
+    "v_subrev_f32 %[b], s83, %[px]\n\t"                                                                \
+    "v_max3_f32 %[k0], %[a], %[b], 0\n\t"                                                              \
+    "v_sub_f32 %[a], s81, %[py]\n\t"                                                                   \
+    "v_subrev_f32 %[b], s84, %[py]\n\t"                                                                \
+    "v_max3_f32 %[c], %[a], %[b], 0\n\t"                                                               \
+    "v_sub_f32 %[a], s82, %[pz]\n\t"                                                                   \
+    "v_subrev_f32 %[b], s85, %[pz]\n\t"                                                                \
+    "v_max3_f32 %[d], %[a], %[b], 0\n\t"                                                               \
+    "v_mul_f32 %[k0], %[k0], %[k0]\n\t"                                                                \
+    "v_fma_f32 %[k0], %[c], %[c], %[k0]\n\t"                                                           \
+    "v_fma_f32 %[k0], %[d], %[d], %[k0]\n\t"                                                           \
+    "v_sub_f32 %[a], s86, %[px]\n\t"                                                                   \
+    "v_subrev_f32 %[b], s89, %[px]\n\t"                                                                \
+    "v_max3_f32 %[k1], %[a], %[b], 0\n\t"                                                              \
+    "v_sub_f32 %[a], s87, %[py]\n\t"                                                                   \
+    "v_subrev_f32 %[b], s90, %[py]\n\t"                                                                \
+    "v_max3_f32 %[c], %[a], %[b], 0\n\t"                                                               \
+    "v_sub_f32 %[a], s88, %[pz]\n\t"                                                                   \
+    "v_subrev_f32 %[b], s91, %[pz]\n\t"                                                                \
+    "v_max3_f32 %[d], %[a], %[b], 0\n\t"                                                               \
+    "v_mul_f32 %[k1], %[k1], %[k1]\n\t"                                                                \
+    "v_fma_f32 %[k1], %[c], %[c], %[k1]\n\t"                                                           \
+    "v_fma_f32 %[k1], %[d], %[d], %[k1]\n\t"                                                           \
+    "v_cmp_le_f32 vcc, %[k0], %[thr]\n\t"                                                              \
+    "s_and_b64 %[m0], vcc, %[drive]\n\t"                                                               \
+    "v_cmp_le_f32 vcc, %[k1], %[thr]\n\t"                                                              \
+    "s_cbranch_scc0 .Lno0%=\n\t"                                                                       \
+    "s_and_b64 %[m1], vcc, %[drive]\n\t"                                                               \
+    "s_cbranch_scc0 .Lonly0%=\n\t"                                                                     \
+    /* both children needed by someone: lanes that need one vote for the nearer */                    \
+    "v_cmp_le_f32 vcc, %[k0], %[k1]\n\t"                                                               \
+    "s_orn2_b64 %[t], vcc, %[m1]\n\t"                                                                  \
+    "s_and_b64 %[t], %[t], %[m0]\n\t"                                                                  \
+    "s_bcnt1_i32_b64 %[t0], %[t]\n\t"                                                                  \
+    "s_or_b64 %[t], %[m0], %[m1]\n\t"                                                                  \
+    "s_bcnt1_i32_b64 %[t1], %[t]\n\t"                                                                  \
+    "s_lshl_b32 %[t0], %[t0], 1\n\t"                                                                   \
+    "s_cmp_ge_u32 %[t0], %[t1]\n\t"          /* SCC = child 0 first */                                 \
+    "s_cselect_b64 vcc, -1, 0\n\t"                                                                     \
+    "v_cndmask_b32 %[a], %[k0], %[k1], vcc\n\t"   /* key of the deferred child */                      \
+    "v_lshl_add_u32 %[b], %[sp], 8, %[sa]\n\t"                                                         \
+    "ds_write_b32 %[b], %[a]\n\t"                                                                      \
+    "s_cselect_b32 %[t1], s93, s92\n\t"      /* deferred reference */                                  \
+    "s_cselect_b32 %[cur], s92, s93\n\t"                                                               \
+    "s_mov_b32 m0, %[sp]\n\t"                                                                          \
+    "s_nop 0\n\t"                                                                                      \
+    "v_writelane_b32 %[refs], %[t1], m0\n\t"                                                           \
+    "s_add_u32 %[sp], %[sp], 1\n\t"                                                                    \
+    "s_branch .Ltop%=\n"                                                                               \
+    ".Lonly0%=:\n\t"                                                                                   \
+    LBMIN_K1                                                                                           \
+    "s_mov_b32 %[cur], s92\n\t"                                                                        \
+    "s_branch .Ltop%=\n"                                                                               \
+    ".Lno0%=:\n\t"                                                                                     \
+    LBMIN_K0                                                                                           \
+    "s_and_b64 %[m1], vcc, %[drive]\n\t"                                                               \
+    "s_cbranch_scc0 .Lnone%=\n\t"                                                                      \
+    "s_mov_b32 %[cur], s93\n\t"                                                                        \
+    "s_branch .Ltop%=\n"                                                                               \
+    ".Lnone%=:\n\t"                                                                                    \
+    LBMIN_K1                                                                                           \
+    ".Lpop%=:\n\t"                                                                                     \
+    "s_cmp_eq_u32 %[sp], 0\n\t"                                                                        \
+    "s_cbranch_scc1 .Lempty%=\n\t"                                                                     \
+    "s_sub_u32 %[sp], %[sp], 1\n\t"                                                                    \
+    "v_lshl_add_u32 %[b], %[sp], 8, %[sa]\n\t"                                                         \
+    "ds_read_b32 %[a], %[b]\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
+    "v_cmp_le_f32 vcc, %[a], %[thr]\n\t"                                                               \
+    "s_and_b64 %[t], vcc, %[drive]\n\t"                                                                \
+    "s_cbranch_scc1 .Ltake%=\n\t"                                                                      \
+    LBMIN_A                                                                                            \
+    "s_branch .Lpop%=\n"                                                                               \
+    ".Ltake%=:\n\t"                                                                                    \
+    "v_readlane_b32 %[cur], %[refs], %[sp]\n\t"                                                        \
+    "s_branch .Ltop%=\n"                                                                               \
+    ".Lempty%=:\n\t"                                                                                   \
+    "s_mov_b32 %[cur], -1\n"                                                                           \
+    ".Ldone%=:\n\t"
+
+template <bool TRACK>
+__device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& refs, float& lb, float thr, float px,
+                                             float py, float pz, unsigned long long drive, const GpuInner* base,
+                                             uint32_t sa) {
+    unsigned long long m0, m1, t;
+    uint32_t t0, t1;
+    float a, b, c, d, k0, k1;
+#define SDFGPU_WALK_OPERANDS                                                                                          \
+    : [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [m0] "=&s"(m0), [m1] "=&s"(m1), [t] "=&s"(t), \
+      [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [k0] "=&v"(k0),          \
+      [k1] "=&v"(k1)                                                                                                  \
+    : [thr] "v"(thr), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [drive] "s"(drive), [base] "s"(base), [sa] "v"(sa)      \
+    : "vcc", "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",       \
+      "s91", "s92", "s93", "s94", "s95"
+    if constexpr (TRACK) {
+        asm volatile(SDFGPU_WALK_ASM("v_min_f32 %[lb], %[lb], %[k0]\n\t", "v_min_f32 %[lb], %[lb], %[k1]\n\t",
+                                     "v_min_f32 %[lb], %[lb], %[a]\n\t") SDFGPU_WALK_OPERANDS);
+    } else {
+        asm volatile(SDFGPU_WALK_ASM("", "", "") SDFGPU_WALK_OPERANDS);
+    }
+#undef SDFGPU_WALK_OPERANDS
+}
+
+template <int MODE, class Acc>
+__device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, float py, float pz,
+                                                unsigned long long drive, float ext, Acc& acc,
+                                                float* __restrict__ stk, uint32_t lane) {
+    uint32_t cur = __builtin_amdgcn_readfirstlane(T.root);
+    if (cur == REF_NONE) return;
+    const float mg = prune_margin<MODE>(T, px, py, pz);
+    uint32_t sp = 0;
+    int refs = 0;   // lane k holds the reference of stack entry k
+    float lb = __builtin_inff();
+    if constexpr (Acc::TRACKS) lb = acc.lb_key;
+    float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+    // LDS byte address of this lane's slot in stack level 0; level l is 256 bytes further
+    const uint32_t sa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)stk + lane * 4u;
+    for (;;) {
+        walk_advance<Acc::TRACKS>(cur, sp, refs, lb, thr, px, py, pz, drive, T.inner, sa);
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        sp = __builtin_amdgcn_readfirstlane(sp);
+        if (cur == REF_NONE) break;
+        const uint32_t id = cur & REF_INDEX;
+        const f32x16 L = load_rec64(T.leaf, id);
+        acc.offer(leaf_eval_rec(L, px, py, pz), id);
+        thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+        cur = REF_POP;
+    }
+    if constexpr (Acc::TRACKS) acc.lb_key = lb;
+}
+
+template <int MODE, bool COUNT, class Acc>
+__device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, unsigned long long drive,
+                                            float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
+                                            WaveCounters& wc) {
+    if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT) nn_traverse_cxx<MODE, COUNT>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else nn_traverse_asm<MODE>(T, px, py, pz, drive, ext, acc, stk, lane);
 }
 
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
@@ -321,6 +528,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
 // take_better induces -- and are padded with (+inf, SDF_NO_PRIM).
 template <int K>
 struct AccK {
+    static constexpr bool TRACKS = false;
     float d[K];
     uint32_t id[K];
     __device__ __forceinline__ void init() {

@@ -1,0 +1,85 @@
+// issue_rates.hip -- how many VALU / SALU instructions per cycle a CU sustains, alone and mixed.
+// Build: hipcc --offload-arch=gfx950 -O2 -o issue_rates issue_rates.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP8(x) x x x x x x x x
+#define REP32(x) REP8(x) REP8(x) REP8(x) REP8(x)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) {
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+    unsigned s0 = (unsigned)iters, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+        if constexpr (KIND == 0) {   // 32 VALU
+            REP8(asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_add_f32 %4, %4, %1"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : );)
+        } else if constexpr (KIND == 1) {   // 32 SALU
+            REP8(asm volatile("s_add_u32 %0, %0, %1\n s_add_u32 %1, %1, %2\n s_add_u32 %2, %2, %3\n s_add_u32 %3, %3, %0"
+                              : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");)
+        } else if constexpr (KIND == 2) {   // 32 VALU + 32 SALU interleaved
+            REP8(asm volatile("v_add_f32 %0, %0, %1\n s_add_u32 %4, %4, %5\n v_add_f32 %2, %2, %1\n s_add_u32 %5, %5, %6\n"
+                              "v_add_f32 %3, %3, %1\n s_add_u32 %6, %6, %7\n v_add_f32 %1, %1, %0\n s_add_u32 %7, %7, %4"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");)
+        } else if constexpr (KIND == 3) {   // 32 VALU + 16 SALU
+            REP8(asm volatile("v_add_f32 %0, %0, %1\n s_add_u32 %4, %4, %5\n v_add_f32 %2, %2, %1\n"
+                              "v_add_f32 %3, %3, %1\n s_add_u32 %6, %6, %7\n v_add_f32 %1, %1, %0"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");)
+        } else if constexpr (KIND == 4) {   // 32 SALU 64-bit mask ops
+            unsigned long long m0 = s0, m1 = s1;
+            REP8(asm volatile("s_and_b64 %0, %0, %1\n s_or_b64 %1, %1, %0\n s_andn2_b64 %0, %0, %1\n s_xor_b64 %1, %1, %0"
+                              : "+s"(m0), "+s"(m1) : : "scc");)
+            s0 += (unsigned)m0; s1 += (unsigned)m1;
+        } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
+            REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
+        }
+    }
+    long long t1 = clock64();
+    float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 + s1 + s2 + s3);
+    if (r == 12345.678f) out[0] = 1;   // keep everything live
+    if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char* name, int valu_per_iter, int salu_per_iter) {
+    const int iters = 2000;
+    for (int wg_per_cu : {1, 2, 4, 8}) {
+        const int blocks = 256 * wg_per_cu;   // 4 waves per WG = 1 per SIMD; wg_per_cu waves per SIMD
+        long long* d;
+        hipMalloc(&d, (1 + blocks * 4) * sizeof(long long));
+        hipMemset(d, 0, (1 + blocks * 4) * sizeof(long long));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 10, 1.0f);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> h(1 + blocks * 4);
+        hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        double avg = 0;
+        for (int i = 1; i < (int)h.size(); ++i) avg += (double)h[i];
+        avg /= (h.size() - 1);
+        const double n_instr = (double)iters * (valu_per_iter + salu_per_iter);
+        // clock64 ticks at 100 MHz (s_memrealtime) or shader clock depending on the build: report both views
+        printf("%-28s waves/SIMD=%d  wall %.3f ms  ticks/wave %.0f  ns per wave-instr %.3f  => per SIMD: %.2f ns/VALU  per CU: %.2f ns/SALU\n",
+               name, wg_per_cu, ms, avg, ms * 1e6 / n_instr,
+               valu_per_iter ? ms * 1e6 / ((double)iters * valu_per_iter * wg_per_cu) : 0.0,
+               salu_per_iter ? ms * 1e6 / ((double)iters * salu_per_iter * wg_per_cu * 4) : 0.0);
+        hipFree(d);
+    }
+}
+
+int main() {
+    run<0>("32 VALU indep", 32, 0);
+    run<5>("32 VALU dependent", 32, 0);
+    run<1>("32 SALU s_add_u32", 0, 32);
+    run<4>("32 SALU 64-bit masks", 0, 32);
+    run<2>("32 VALU + 32 SALU", 32, 32);
+    run<3>("32 VALU + 16 SALU", 32, 16);
+    return 0;
+}
