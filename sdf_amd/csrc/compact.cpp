@@ -58,15 +58,19 @@ bool rigid3(const float* m, double tol) {
     return true;
 }
 
-float round_down(double x) {
-    float f = (float)x;
-    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
-    return f;
-}
 float round_up(double x) {
     float f = (float)x;
     if ((double)f < x) f = std::nextafterf(f, INFINITY);
     return f;
+}
+
+// Centre / half-extent form of a box, rounded so that [c-h, c+h] contains it.
+void set_box(float c[3], float h[3], const Box3& b) {
+    for (int a = 0; a < 3; ++a) {
+        c[a] = (float)(0.5 * (b.lo[a] + b.hi[a]));
+        const double cd = (double)c[a];
+        h[a] = round_up(std::max(b.hi[a] - cd, cd - b.lo[a]));
+    }
 }
 
 // World AABB of one primitive from its world->primitive transform.
@@ -144,15 +148,17 @@ uint32_t emit(Ctx& c, uint32_t i, Box3* box, uint32_t* depth) {
     } else {
         GpuInner& g = c.out->inner[self];
         std::memset(&g, 0, sizeof g);
-        for (int a = 0; a < 3; ++a) {
-            if (c.bounds == SDFGPU_BOUNDS_AABB) {
-                g.lo0[a] = round_down(b0.lo[a]); g.hi0[a] = round_up(b0.hi[a]);
-                g.lo1[a] = round_down(b1.lo[a]); g.hi1[a] = round_up(b1.hi[a]);
+        if (c.bounds == SDFGPU_BOUNDS_AABB) {
+            set_box(g.c0, g.h0, b0);
+            set_box(g.c1, g.h1, b1);
+            for (int a = 0; a < 3; ++a) {
                 box->lo[a] = std::min(b0.lo[a], b1.lo[a]);
                 box->hi[a] = std::max(b0.hi[a], b1.hi[a]);
-            } else {  // NONE: boxes that contain everything -> nothing is ever pruned
-                g.lo0[a] = g.lo1[a] = -FLT_MAX;
-                g.hi0[a] = g.hi1[a] = FLT_MAX;
+            }
+        } else {  // NONE: boxes that contain everything -> nothing is ever pruned
+            for (int a = 0; a < 3; ++a) {
+                g.c0[a] = g.c1[a] = 0.f;
+                g.h0[a] = g.h1[a] = FLT_MAX;
             }
         }
         g.ref0 = r0;
@@ -252,9 +258,9 @@ uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, uint32_t b
     const uint32_t r1 = build_sah(p, mid, hi, budget - 1, out, &b1, &d1);
     GpuInner& g = out.inner[self];
     std::memset(&g, 0, sizeof g);
+    set_box(g.c0, g.h0, b0);
+    set_box(g.c1, g.h1, b1);
     for (int a = 0; a < 3; ++a) {
-        g.lo0[a] = round_down(b0.lo[a]); g.hi0[a] = round_up(b0.hi[a]);
-        g.lo1[a] = round_down(b1.lo[a]); g.hi1[a] = round_up(b1.hi[a]);
         box->lo[a] = std::min(b0.lo[a], b1.lo[a]);
         box->hi[a] = std::max(b0.hi[a], b1.hi[a]);
     }

@@ -30,10 +30,12 @@ struct alignas(64) GpuLeaf {
 };
 static_assert(sizeof(GpuLeaf) == 64, "GpuLeaf is one 64-byte line");
 
-// Internal node, AABB mode: world-space boxes of both children.
+// Internal node, AABB / BVH mode: world-space boxes of both children as centre
+// + half extent (distance per axis = max(|p - c| - h, 0): three full-rate VALU
+// operations, against two subtractions and a three-operand max for lo/hi).
 struct alignas(64) GpuInner {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
+    float c0[3], h0[3];
+    float c1[3], h1[3];
     uint32_t ref0, ref1;
     uint32_t pad[2];
 };

@@ -71,12 +71,13 @@ __device__ __forceinline__ float min_nn(float a, float b) { return a < b ? a : b
 
 // --------------------------------------------------------------- bounds ---
 
-// Squared distance to an axis-aligned box (0 inside).  Not exact by design.
-__device__ __forceinline__ float aabb_dist2(const float* __restrict__ lo, const float* __restrict__ hi, float px,
+// Squared distance to an axis-aligned box (0 inside), box as centre + half
+// extent.  Not exact by design (the prune margin covers its rounding).
+__device__ __forceinline__ float aabb_dist2(const float* __restrict__ c, const float* __restrict__ h, float px,
                                             float py, float pz) {
-    float dx = __builtin_fmaxf(__builtin_fmaxf(lo[0] - px, px - hi[0]), 0.f);
-    float dy = __builtin_fmaxf(__builtin_fmaxf(lo[1] - py, py - hi[1]), 0.f);
-    float dz = __builtin_fmaxf(__builtin_fmaxf(lo[2] - pz, pz - hi[2]), 0.f);
+    float dx = __builtin_fmaxf(__builtin_fabsf(px - c[0]) - h[0], 0.f);
+    float dy = __builtin_fmaxf(__builtin_fabsf(py - c[1]) - h[1], 0.f);
+    float dz = __builtin_fmaxf(__builtin_fabsf(pz - c[2]) - h[2], 0.f);
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
@@ -235,10 +236,10 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
             r1 = N->ref1;
         } else {
             const f32x16 N = load_rec64(T.inner, cur);
-            const float lo0[3] = {N[0], N[1], N[2]}, hi0[3] = {N[3], N[4], N[5]};
-            const float lo1[3] = {N[6], N[7], N[8]}, hi1[3] = {N[9], N[10], N[11]};
-            k0 = aabb_dist2(lo0, hi0, px, py, pz);
-            k1 = aabb_dist2(lo1, hi1, px, py, pz);
+            const float c0[3] = {N[0], N[1], N[2]}, h0[3] = {N[3], N[4], N[5]};
+            const float c1[3] = {N[6], N[7], N[8]}, h1[3] = {N[9], N[10], N[11]};
+            k0 = aabb_dist2(c0, h0, px, py, pz);
+            k1 = aabb_dist2(c1, h1, px, py, pz);
             r0 = rec_bits(N[12]);
             r1 = rec_bits(N[13]);
         }
@@ -325,30 +326,30 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_lshl_b32 %[t0], %[cur], 6\n\t"                                                                  \
     "s_load_dwordx16 s[80:95], %[base], %[t0]\n\t"                                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
-    "v_sub_f32 %[a], s80, %[px]\n\t"                                                                   \
-    "v_subrev_f32 %[b], s83, %[px]\n\t"                                                                \
-    "v_max3_f32 %[k0], %[a], %[b], 0\n\t"                                                              \
-    "v_sub_f32 %[a], s81, %[py]\n\t"                                                                   \
-    "v_subrev_f32 %[b], s84, %[py]\n\t"                                                                \
-    "v_max3_f32 %[c], %[a], %[b], 0\n\t"                                                               \
-    "v_sub_f32 %[a], s82, %[pz]\n\t"                                                                   \
-    "v_subrev_f32 %[b], s85, %[pz]\n\t"                                                                \
-    "v_max3_f32 %[d], %[a], %[b], 0\n\t"                                                               \
-    "v_mul_f32 %[k0], %[k0], %[k0]\n\t"                                                                \
-    "v_fma_f32 %[k0], %[c], %[c], %[k0]\n\t"                                                           \
-    "v_fma_f32 %[k0], %[d], %[d], %[k0]\n\t"                                                           \
-    "v_sub_f32 %[a], s86, %[px]\n\t"                                                                   \
-    "v_subrev_f32 %[b], s89, %[px]\n\t"                                                                \
-    "v_max3_f32 %[k1], %[a], %[b], 0\n\t"                                                              \
-    "v_sub_f32 %[a], s87, %[py]\n\t"                                                                   \
-    "v_subrev_f32 %[b], s90, %[py]\n\t"                                                                \
-    "v_max3_f32 %[c], %[a], %[b], 0\n\t"                                                               \
-    "v_sub_f32 %[a], s88, %[pz]\n\t"                                                                   \
-    "v_subrev_f32 %[b], s91, %[pz]\n\t"                                                                \
-    "v_max3_f32 %[d], %[a], %[b], 0\n\t"                                                               \
-    "v_mul_f32 %[k1], %[k1], %[k1]\n\t"                                                                \
-    "v_fma_f32 %[k1], %[c], %[c], %[k1]\n\t"                                                           \
-    "v_fma_f32 %[k1], %[d], %[d], %[k1]\n\t"                                                           \
+    "v_subrev_f32 %[a], s80, %[px]\n\t"                                                              \
+    "v_subrev_f32 %[b], s81, %[py]\n\t"                                                              \
+    "v_subrev_f32 %[c], s82, %[pz]\n\t"                                                              \
+    "v_sub_f32 %[a], |%[a]|, s83\n\t"                                                                \
+    "v_sub_f32 %[b], |%[b]|, s84\n\t"                                                                \
+    "v_sub_f32 %[c], |%[c]|, s85\n\t"                                                                \
+    "v_max_f32 %[a], 0, %[a]\n\t"                                                                    \
+    "v_max_f32 %[b], 0, %[b]\n\t"                                                                    \
+    "v_max_f32 %[c], 0, %[c]\n\t"                                                                    \
+    "v_mul_f32 %[k0], %[a], %[a]\n\t"                                                                \
+    "v_fmac_f32 %[k0], %[b], %[b]\n\t"                                                               \
+    "v_fmac_f32 %[k0], %[c], %[c]\n\t"                                                               \
+    "v_subrev_f32 %[a], s86, %[px]\n\t"                                                              \
+    "v_subrev_f32 %[b], s87, %[py]\n\t"                                                              \
+    "v_subrev_f32 %[c], s88, %[pz]\n\t"                                                              \
+    "v_sub_f32 %[a], |%[a]|, s89\n\t"                                                                \
+    "v_sub_f32 %[b], |%[b]|, s90\n\t"                                                                \
+    "v_sub_f32 %[c], |%[c]|, s91\n\t"                                                                \
+    "v_max_f32 %[a], 0, %[a]\n\t"                                                                    \
+    "v_max_f32 %[b], 0, %[b]\n\t"                                                                    \
+    "v_max_f32 %[c], 0, %[c]\n\t"                                                                    \
+    "v_mul_f32 %[k1], %[a], %[a]\n\t"                                                                \
+    "v_fmac_f32 %[k1], %[b], %[b]\n\t"                                                               \
+    "v_fmac_f32 %[k1], %[c], %[c]\n\t"                                                               \
     "v_cmp_le_f32 vcc, %[k0], %[thr]\n\t"                                                              \
     "s_and_b64 %[m0], vcc, %[drive]\n\t"                                                               \
     "v_cmp_le_f32 vcc, %[k1], %[thr]\n\t"                                                              \

@@ -32,6 +32,28 @@ __global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) 
             REP8(asm volatile("s_and_b64 %0, %0, %1\n s_or_b64 %1, %1, %0\n s_andn2_b64 %0, %0, %1\n s_xor_b64 %1, %1, %0"
                               : "+s"(m0), "+s"(m1) : : "scc");)
             s0 += (unsigned)m0; s1 += (unsigned)m1;
+        } else if constexpr (KIND == 6) {   // 32 packed adds (64 flops-lanes)
+            double d0 = __hiloint2double(__float_as_int(a0), __float_as_int(a1)), d1 = __hiloint2double(__float_as_int(a2), __float_as_int(a3));
+            double d2 = __hiloint2double(__float_as_int(a4), __float_as_int(a5)), d3 = __hiloint2double(__float_as_int(a6), __float_as_int(a7));
+            REP8(asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %2, %2, %1\n v_pk_add_f32 %3, %3, %1\n v_pk_add_f32 %1, %1, %0"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : );)
+            a0 += (float)d0 + (float)d1 + (float)d2 + (float)d3;
+        } else if constexpr (KIND == 7) {   // 32 packed fma
+            double d0 = __hiloint2double(__float_as_int(a0), __float_as_int(a1)), d1 = __hiloint2double(__float_as_int(a2), __float_as_int(a3));
+            double d2 = __hiloint2double(__float_as_int(a4), __float_as_int(a5)), d3 = __hiloint2double(__float_as_int(a6), __float_as_int(a7));
+            REP8(asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %2, %2, %1, %3\n v_pk_fma_f32 %3, %3, %1, %0\n v_pk_fma_f32 %1, %1, %0, %2"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : );)
+            a0 += (float)d0 + (float)d1 + (float)d2 + (float)d3;
+        } else if constexpr (KIND == 8) {   // 32 max3
+            REP8(asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %2, %2, %1, %3\n v_max3_f32 %3, %3, %1, %0\n v_max3_f32 %1, %1, %0, %2"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : );)
+        } else if constexpr (KIND == 9) {   // 32 pk_add with SGPR pair source
+            double d0 = __hiloint2double(__float_as_int(a0), __float_as_int(a1)), d1 = __hiloint2double(__float_as_int(a2), __float_as_int(a3));
+            double d2 = __hiloint2double(__float_as_int(a4), __float_as_int(a5)), d3 = __hiloint2double(__float_as_int(a6), __float_as_int(a7));
+            unsigned long long sp = ((unsigned long long)s0 << 32) | s1;
+            REP8(asm volatile("v_pk_add_f32 %0, %4, %1 op_sel_hi:[1,0]\n v_pk_add_f32 %2, %4, %1 op_sel_hi:[1,0]\n v_pk_add_f32 %3, %4, %1 op_sel_hi:[1,0]\n v_pk_add_f32 %1, %4, %0 op_sel_hi:[1,0]"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "s"(sp));)
+            a0 += (float)d0 + (float)d1 + (float)d2 + (float)d3;
         } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
             REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
         }
@@ -79,6 +101,10 @@ int main() {
     run<5>("32 VALU dependent", 32, 0);
     run<1>("32 SALU s_add_u32", 0, 32);
     run<4>("32 SALU 64-bit masks", 0, 32);
+    run<6>("32 v_pk_add_f32", 32, 0);
+    run<7>("32 v_pk_fma_f32", 32, 0);
+    run<9>("32 v_pk_add_f32 sgpr src", 32, 0);
+    run<8>("32 v_max3_f32", 32, 0);
     run<2>("32 VALU + 32 SALU", 32, 32);
     run<3>("32 VALU + 16 SALU", 32, 16);
     return 0;
