@@ -148,6 +148,29 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
     return out
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE are collected in separate runs by tools/profile_bench.sh;
+    bench.py itself cannot read counters).  FETCH_SIZE/WRITE_SIZE are in KiB; the reads of
+    this kernel are 64-byte scalar-cache lines, not the wide streaming reads whose FETCH_SIZE
+    gfx950 halves, so no doubling is applied (MI355X_MICROARCH.md, HBM section)."""
+    import glob
+    import json as _json
+    best = None
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_by_kernel.json"))):
+        try:
+            with open(path) as f:
+                d = _json.load(f)
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if "render_pass_kernel<1, false, true>" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                best = (path, (v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0)
+    if best is None:
+        return None, "no PMC profile committed"
+    return best[1], "bytes per launch, FETCH_SIZE + WRITE_SIZE from " + os.path.relpath(best[0], os.path.dirname(os.path.abspath(__file__)))
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -298,14 +321,16 @@ def main():
             flops = W.algorithmic_flops(st)
             achieved = flops / (k_avg * 1e-3) / 1e12
             bytes_alg = npix * 21 + int(info.device_bytes)
+            traffic, traffic_note = profiled_traffic()
             line["roofline"] = {
                 "bound": "valu",
                 "achieved": achieved,
                 "peak": VALU_PEAK_UNFUSED_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / VALU_PEAK_UNFUSED_TFLOPS,
-                "traffic": None,
-                "kernel": "render_kernel<AABB>",
+                "traffic": traffic,
+                "traffic_note": traffic_note,
+                "kernel": "sdfgpu::render_pass_kernel<1, false, true>",
                 "kernel_ms_avg": k_avg,
                 "algorithmic_flops_per_launch": flops,
                 "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS,
