@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--skip-ext", type=float, default=0.0, help="SDFGPU_OPT_SKIP_EXTENSION (<0: half the mean primitive size)")
     ap.add_argument("--compaction", action="store_true", help="multi-pass march with ray compaction (SDFGPU_OPT_COMPACTION=1)")
     ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (1 = strictly one after the other)")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="diagnostic (1 GPU): render only rank 0's tile share of an N-rank frame, no gather")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
     ap.add_argument("--knn-points", type=int, default=10_000_000)
@@ -230,7 +232,15 @@ def main():
     o_hit = slots[0].o_hit
     torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and a.emulate_world > 1:
+        # diagnostic only: rank 0's share of an N-rank frame (no gather), to size the pipeline depth
+        first, stride, cnt = P.rank_tiles(0, a.emulate_world, tiles)
+
+        def step(k=0):
+            sl = slots[k % depth]
+            gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, sl.o_hit.data_ptr(), sl.o_depth.data_ptr(),
+                                 sl.o_normal.data_ptr(), sl.o_prim.data_ptr(), sl.stream.cuda_stream)
+    elif world == 1:
         def step(k=0):
             sl = slots[k % depth]
             gpu.render_dev(cam, w, h, mp, sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(),
