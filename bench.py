@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none", "bvh"])
     ap.add_argument("--skip-ext", type=float, default=0.0, help="SDFGPU_OPT_SKIP_EXTENSION (<0: half the mean primitive size)")
     ap.add_argument("--compaction", action="store_true", help="multi-pass march with ray compaction (SDFGPU_OPT_COMPACTION=1)")
-    ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (1 = strictly one after the other)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="frames in flight (1 = strictly one after the other; 0 = default: 2 on one GPU, "
+                         "min(8, N + 2) on N GPUs, where a rank's tile share no longer fills its GPU)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="diagnostic (1 GPU): render only rank 0's tile share of an N-rank frame, no gather")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -208,7 +210,7 @@ def main():
     # stream and output buffers, so the drain of one frame (a few long grazing rays on a mostly
     # idle GPU) overlaps the start of the next.  Frames are independent; each is complete
     # (march + normals [+ gather + assembly]) before its slot is reused.
-    depth = max(1, a.pipeline)
+    depth = a.pipeline if a.pipeline > 0 else (2 if world == 1 else min(8, world + 2))
     main_stream = torch.cuda.current_stream()
     streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(depth - 1)]
 
