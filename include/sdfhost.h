@@ -66,6 +66,11 @@ float sdfhost_default_extent(uint32_t n);
 /* SdfNode accessors */
 uint32_t sdfhost_node_num_slots(const sdfhost_node* n);
 int sdfhost_node_bbox(const sdfhost_node* n, SdfBoundingBoxBlock* out);   /* node.bbox.unwrap().get_bbox_block() */
+/* SdfNode::nearest_neighbor (node.rs:331-368): the crate's recursive n-ary branch-and-prune
+ * query on the scene tree itself (host code there and here).  out_prim (optional) receives the
+ * pre-order ordinal of the returned primitive among the tree's primitives, SDF_NO_PRIM when the
+ * query returned no primitive (distance +inf).  0 on success, -1 with sdfhost_last_error. */
+int sdfhost_node_nearest_neighbor(const sdfhost_node* n, const float p[3], float* out_dist, uint32_t* out_prim);
 void sdfhost_node_free(sdfhost_node* n);
 
 /* SdfNode::expanded() -- node.rs:209 */

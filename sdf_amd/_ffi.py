@@ -167,6 +167,7 @@ HOST_SYMBOLS = {
     "sdfhost_default_extent": (_f, [_u32]),
     "sdfhost_node_num_slots": (_u32, [_vp]),
     "sdfhost_node_bbox": (_i, [_vp, _vp]),
+    "sdfhost_node_nearest_neighbor": (_i, [_vp, _fp, _fp, C.POINTER(_u32)]),
     "sdfhost_node_free": (None, [_vp]),
     "sdfhost_expanded_new": (_vp, [_vp, C.POINTER(HostOptions)]),
     "sdfhost_expanded_free": (None, [_vp]),

@@ -121,6 +121,36 @@ int sdfhost_node_bbox(const sdfhost_node* n, SdfBoundingBoxBlock* out) {
     return 0;
 }
 
+namespace {
+// pre-order ordinal of `target` among the primitives under `n`
+bool prim_ordinal(const SdfNode& n, const SdfNode* target, uint32_t* next) {
+    if (n.is_primitive()) {
+        if (&n == target) return true;
+        *next += 1;
+        return false;
+    }
+    for (const SdfNode& c : n.slots)
+        if (prim_ordinal(c, target, next)) return true;
+    return false;
+}
+}  // namespace
+
+int sdfhost_node_nearest_neighbor(const sdfhost_node* n, const float p[3], float* out_dist, uint32_t* out_prim) {
+    if (!n || !p || !out_dist) { g_err = "null argument"; return -1; }
+    try {
+        const NnResult r = n->n.nearest_neighbor(Vec3(p[0], p[1], p[2]));
+        *out_dist = r.distance;
+        if (out_prim) {
+            uint32_t ord = 0;
+            *out_prim = (r.node && r.node->is_primitive() && prim_ordinal(n->n, r.node, &ord)) ? ord : SDF_NO_PRIM;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 void sdfhost_node_free(sdfhost_node* n) { delete n; }
 
 sdfhost_expanded* sdfhost_expanded_new(const sdfhost_node* n, const sdfhost_options* opts) {

@@ -324,6 +324,54 @@ ExpandedSdfNode SdfSphere::expand(const SdfNode& node, const BuildOptions&) cons
 SdfBoundingBox SdfBox::get_bbox(const std::vector<SdfBoundingBox>&, const BuildOptions&) const {
     return SdfBoundingBox::from_transform(Transform::from_scale(half));
 }
+// ---- recursive query, node.rs:250-267, 331-368 -------------------------------
+bool SdfNode::could_contain(Vec3 p) const {
+    if (!is_finished()) throw std::logic_error("Tried testing point-in-bbox on an unfinished SDF node!");
+    return bbox->contains(p);
+}
+
+NodeDistInfo SdfNode::bbox_dist_info(Vec3 p) const {
+    if (!is_finished()) throw std::logic_error("Tried getting bounding-box distance info on an unfinished SDF node!");
+    return NodeDistInfo{bbox->distance_to(p), bbox->max_distance(p)};
+}
+
+namespace {
+// CmpFloat (obb.rs:26-41): partial_cmp().unwrap_or(Equal) -- a NaN compares equal to everything.
+inline bool cmpfloat_less(float a, float b) { return a < b; }
+}  // namespace
+
+NnResult SdfNode::nearest_neighbor(Vec3 p) const {
+    if (is_primitive()) {   // :332-337
+        const Vec4 q = bbox.value().in_box_trans_basis(Vec4(p, 1.f));
+        return NnResult{this, intern->distance_to(Vec3(q.x, q.y, q.z))};
+    }
+    // :338-341 bounds of every slot at the point as given to this node
+    std::vector<std::pair<size_t, NodeDistInfo>> bounds;
+    bounds.reserve(slots.size());
+    for (size_t i = 0; i < slots.size(); ++i) bounds.emplace_back(i, slots[i].bbox_dist_info(p));
+    if (bounds.empty()) throw std::logic_error("nearest_neighbor on an operation without slots");   // .min().unwrap()
+    // :342-344 smallest MAXDIST (Iterator::min keeps the FIRST of equal minima)
+    float min_maxdist = bounds[0].second.max_bound;
+    for (size_t i = 1; i < bounds.size(); ++i)
+        if (cmpfloat_less(bounds[i].second.max_bound, min_maxdist)) min_maxdist = bounds[i].second.max_bound;
+    // :345 sort_unstable_by_key(min_bound): order among equal keys is unspecified in the crate; here by slot index
+    std::stable_sort(bounds.begin(), bounds.end(), [](const auto& a, const auto& b) {
+        return cmpfloat_less(a.second.min_bound, b.second.min_bound);
+    });
+    // :346-367 take_while(min_bound < min_maxdist), fold keeping the strictly smaller distance
+    NnResult accum{this, INFINITY};
+    const Vec4 q = bbox.value().in_box_trans_basis(Vec4(p, 1.f));
+    const Vec3 local(q.x, q.y, q.z);
+    for (const auto& [i, bound] : bounds) {
+        if (!(bound.min_bound < min_maxdist)) break;
+        if (bound.min_bound > accum.distance) continue;
+        const SdfNode& child = slots[i];
+        const NnResult child_nn = child.nearest_neighbor(child.downtree(local));
+        if (child_nn.distance < accum.distance) accum = child_nn;
+    }
+    return accum;
+}
+
 float SdfBox::distance_to(Vec3 p) const {
     float qx = std::fabs(p.x) - half.x, qy = std::fabs(p.y) - half.y, qz = std::fabs(p.z) - half.z;
     float l = length(Vec3(std::max(qx, 0.f), std::max(qy, 0.f), std::max(qz, 0.f)));

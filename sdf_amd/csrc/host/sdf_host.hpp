@@ -166,6 +166,16 @@ struct ExpandedSdfNode {
     SdfTreeBuffer make_buffer(const BuildOptions& o = BuildOptions()) const;          // :75-138
 };
 
+struct SdfNode;
+// node.rs:10-18
+struct NodeDistInfo {
+    float min_bound, max_bound;
+};
+struct NnResult {
+    const SdfNode* node;
+    float distance;
+};
+
 // node.rs:141-235
 struct SdfNode {
     std::vector<SdfNode> slots;
@@ -185,6 +195,12 @@ struct SdfNode {
     bool is_finished() const { return bbox.has_value(); }
     bool is_primitive() const { return intern->get_info().is_primitive; }
     bool is_empty() const { return slots.empty(); }
+    Vec3 downtree(Vec3 p) const { return intern->downtree_transform(p); }        // node.rs:225-227
+    bool could_contain(Vec3 p) const;                                            // node.rs:250-256
+    NodeDistInfo bbox_dist_info(Vec3 p) const;                                   // node.rs:258-267
+    // node.rs:331-368: the crate's recursive n-ary branch-and-prune query on the
+    // scene tree itself (the path its own tests exercise).  Host code, as in the crate.
+    NnResult nearest_neighbor(Vec3 p) const;
 };
 
 // node.rs:371-414.  The crate's asserts/expects become std::logic_error.

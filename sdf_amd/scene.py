@@ -200,6 +200,15 @@ class SdfNode:
             raise SdfError(_host_err())
         return out[0]
 
+    def nearest_neighbor(self, point):
+        """node.rs:331-368 (recursive n-ary query, host).  Returns (distance, primitive ordinal)."""
+        p = np.ascontiguousarray(point, dtype=np.float32).reshape(3)
+        d = C.c_float()
+        i = C.c_uint32()
+        if _ffi.load_library().sdfhost_node_nearest_neighbor(self._h, _ffi.fptr(p), C.byref(d), C.byref(i)) != 0:
+            raise SdfError(_host_err())
+        return float(np.float32(d.value)), int(i.value)
+
     def expanded(self):
         e = _ffi.load_library().sdfhost_expanded_new(self._h, _opts(self._opts))
         if not e:

@@ -168,3 +168,58 @@ def test_scene_is_deterministic_and_save_load_roundtrip(tmp_path):
     a.save(p)
     c = S.SdfTreeBuffer.load(p)
     assert c.downtree_buffer.tobytes() == a.downtree_buffer.tobytes() and c.buffer_len == a.buffer_len
+
+
+# ---- SdfNode::nearest_neighbor (node.rs:331-368): the crate's recursive n-ary query ----
+
+def _random_prim(rng, L):
+    if rng.random() < 0.5:
+        e = S.SdfSphere(float(rng.uniform(0.5, 2.0)))
+    else:
+        e = S.SdfBox(tuple(float(v) for v in rng.uniform(0.5, 2.0, 3)))
+    t = S.Transform.from_translation(tuple(float(v) for v in rng.uniform(-L, L, 3)))
+    return S.SdfBuilder.primitive(e).transform(t)
+
+
+def _union_of(builders):
+    b = builders[0].operation(S.SdfUnion(0.0))
+    for x in builders[1:]:
+        b = b.with_(x)
+    return b
+
+
+def test_recursive_query_single_primitive_like_the_crates_own_tests():
+    # node.rs:506-580 (test_dense_nn_single_uni / _dir): one transformed sphere, |p - c| - r
+    from oracle import oracle as O
+    from conftest import bits, make_points
+    node = S.SdfBuilder.primitive(S.SdfSphere(1.5)).transform(S.Transform.from_translation((3.0, -2.0, 5.0))).finalize()
+    pts = make_points(200, 10.0, 3)
+    buf = node.expanded().make_buffer()
+    d0, _ = O.nearest(buf, pts, mode=O.MODE_FAUX)
+    for p, want in zip(pts, d0):
+        d, i = node.nearest_neighbor(p[:3])
+        assert bits(np.float32(d)) == bits(want) and i == 0
+        c = np.array([3.0, -2.0, 5.0])
+        assert abs(d - (np.linalg.norm(p[:3].astype(np.float64) - c) - 1.5)) < 1e-4
+
+
+@pytest.mark.parametrize("shape", ["flat", "nested"])
+def test_recursive_query_equals_the_flat_query(shape):
+    # the n-ary walk over the scene tree and the flat walk over its buffer are two
+    # evaluations of the same union: identical distance bits at every point
+    from oracle import oracle as O
+    from conftest import bits, make_points
+    rng = np.random.default_rng(11)
+    L = 20.0
+    if shape == "flat":
+        node = _union_of([_random_prim(rng, L) for _ in range(40)]).finalize()
+    else:
+        groups = [_union_of([_random_prim(rng, L) for _ in range(int(rng.integers(2, 7)))]) for _ in range(8)]
+        node = _union_of(groups + [_random_prim(rng, L)]).finalize()
+    buf = node.expanded().make_buffer()
+    pts = make_points(1500, L, 5)
+    d0, _ = O.nearest(buf, pts, mode=O.MODE_EXHAUSTIVE)
+    got = np.array([node.nearest_neighbor(p[:3])[0] for p in pts], np.float32)
+    assert np.array_equal(bits(got), bits(d0))
+    prims = {node.nearest_neighbor(p[:3])[1] for p in pts[:300]}
+    assert len(prims) > 3 and all(0 <= i < buf.n_prims for i in prims)
