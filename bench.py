@@ -346,6 +346,8 @@ def main():
                 "kernel_ms_avg": k_avg,
                 "algorithmic_flops_per_launch": flops,
                 "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS,
+                # the same flops over the pipelined frame time (frames in flight fill the drain)
+                "frac_at_throughput": flops / (ms * 1e-3) / 1e12 / VALU_PEAK_UNFUSED_TFLOPS,
                 "hbm": {"algorithmic_bytes_per_launch": bytes_alg,
                         "achieved_GBs": bytes_alg / (k_avg * 1e-3) / 1e9,
                         "peak_GBs": HBM_PEAK_GBS,
