@@ -251,20 +251,23 @@ def main():
         first, stride, cnt = P.rank_tiles(rank, world, tiles)
         nbytes = P.packed_bytes(world, tiles)
 
+        # device addresses of every plane, once (the buffers live as long as the slots)
+        for sl in slots:
+            sl.mine_ptrs = tuple(t.data_ptr() for t in P.planes(sl.mine, world, tiles))
+            sl.part_ptrs = []
+            for r in range(world):
+                part = P.planes(sl.gathered[r * nbytes: (r + 1) * nbytes], world, tiles)
+                sl.part_ptrs.append((P.rank_tiles(r, world, tiles), tuple(t.data_ptr() for t in part)))
+            sl.out_ptrs = (sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(), sl.o_prim.data_ptr())
+
         def step(k=0):
             sl = slots[k % depth]
             with torch.cuda.stream(sl.stream):
-                m_hit, m_depth, m_normal, m_prim = P.planes(sl.mine, world, tiles)
-                gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, m_hit.data_ptr(), m_depth.data_ptr(),
-                                     m_normal.data_ptr(), m_prim.data_ptr(), sl.stream.cuda_stream)
+                gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, *sl.mine_ptrs, sl.stream.cuda_stream)
                 dist.all_gather_into_tensor(sl.gathered, sl.mine)
                 if rank == 0:
-                    for r in range(world):
-                        g_hit, g_depth, g_normal, g_prim = P.planes(sl.gathered[r * nbytes: (r + 1) * nbytes], world, tiles)
-                        rf, rs, rc = P.rank_tiles(r, world, tiles)
-                        gpu.untile_dev(w, h, rf, rs, rc, g_hit.data_ptr(), g_depth.data_ptr(),
-                                       g_normal.data_ptr(), g_prim.data_ptr(), sl.o_hit.data_ptr(), sl.o_depth.data_ptr(),
-                                       sl.o_normal.data_ptr(), sl.o_prim.data_ptr(), sl.stream.cuda_stream)
+                    for (rf, rs, rc), ptrs in sl.part_ptrs:
+                        gpu.untile_dev(w, h, rf, rs, rc, *ptrs, *sl.out_ptrs, sl.stream.cuda_stream)
 
     def barrier():
         if dist is not None:
@@ -296,6 +299,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    assembly_check = None
+    if world > 1 and rank == 0:
+        # the frame assembled from every rank's tiles must equal rank 0's own whole-frame render
+        chk = [torch.empty_like(t) for t in (slots[0].o_hit, slots[0].o_depth, slots[0].o_normal, slots[0].o_prim)]
+        gpu.render_dev(cam, w, h, mp, chk[0].data_ptr(), chk[1].data_ptr(), chk[2].data_ptr(), chk[3].data_ptr(),
+                       main_stream.cuda_stream)
+        torch.cuda.synchronize()
+        same = (torch.equal(chk[0], slots[0].o_hit) and torch.equal(chk[3], slots[0].o_prim)
+                and torch.equal(chk[1].view(torch.int32), slots[0].o_depth.view(torch.int32))
+                and torch.equal(chk[2].view(torch.int32), slots[0].o_normal.view(torch.int32)))
+        assembly_check = "bit-identical to a single-GPU render" if same else "MISMATCH"
+
     line = None
     if rank == 0:
         ms = elapsed / a.steps * 1e3
@@ -325,6 +340,7 @@ def main():
                 "frames_in_flight": depth,
                 "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL all-gather",
                 "hit_fraction": hit_frac,
+                "assembly_check": assembly_check,
             },
         }
         if world == 1:

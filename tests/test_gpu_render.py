@@ -202,3 +202,42 @@ def test_compaction_two_frames_in_flight(gpu):
             _compare(got, ref)
     finally:
         gpu.set_compaction(False)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_packed_planes_assembly_as_in_bench(gpu, world):
+    # the multi-GPU data path of bench.py on one GPU: every rank's tiles into its packed
+    # [depth | normal | prim | hit] buffer, the buffers laid end to end as the all-gather
+    # leaves them, untile from each chunk -> the whole-frame render
+    import torch
+    from sdf_amd import partition as P
+
+    n, w, h = 200, 173, 99          # ragged: partial tiles on both edges, tile count not a multiple of world
+    buf = S.random_scene_buffer(n, 77)
+    cam, mp = scene_camera(n, w, h)
+    gpu.upload_tree(buf)
+    full = gpu.render(cam, w, h, mp)
+    tiles = P.n_tiles(w, h)
+    nbytes = P.packed_bytes(world, tiles)
+    dev = torch.device("cuda:0")
+    gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        mine = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        first, stride, cnt = P.rank_tiles(r, world, tiles)
+        ptrs = tuple(t.data_ptr() for t in P.planes(mine, world, tiles))
+        gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, *ptrs, stream)
+        gathered[r * nbytes:(r + 1) * nbytes] = mine
+    o_hit = torch.zeros(w * h, dtype=torch.uint8, device=dev)
+    o_depth = torch.zeros(w * h, dtype=torch.float32, device=dev)
+    o_normal = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+    o_prim = torch.zeros(w * h, dtype=torch.int32, device=dev)
+    for r in range(world):
+        part = P.planes(gathered[r * nbytes:(r + 1) * nbytes], world, tiles)
+        rf, rs, rc = P.rank_tiles(r, world, tiles)
+        gpu.untile_dev(w, h, rf, rs, rc, *(t.data_ptr() for t in part), o_hit.data_ptr(), o_depth.data_ptr(),
+                       o_normal.data_ptr(), o_prim.data_ptr(), stream)
+    torch.cuda.synchronize()
+    got = {"hit": o_hit.cpu().numpy(), "depth": o_depth.cpu().numpy(),
+           "normal": o_normal.cpu().numpy().reshape(-1, 3), "prim": o_prim.cpu().numpy().view(np.uint32)}
+    _compare(got, full)
