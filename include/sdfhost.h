@@ -45,6 +45,10 @@ sdfhost_builder* sdfhost_primitive_sphere(float radius, const sdfhost_options* o
 sdfhost_builder* sdfhost_primitive_box(float hx, float hy, float hz, const sdfhost_options* opts);
 /* .operation(SdfUnion{smooth_radius}) -- node.rs:396, elements.rs:157; consumes b */
 sdfhost_builder* sdfhost_operation_union(sdfhost_builder* b, float smooth_radius);
+/* SdfBuilder::operation(SdfCaaClone { displacement, neg_limit, pos_limit }) (elements.rs:215-262).
+ * The flat query evaluates a clone subtree to +inf as written (faux_shader.rs:90); see DESIGN.md. */
+sdfhost_builder* sdfhost_operation_caa_clone(sdfhost_builder* b, const float displacement[3], const float neg_limit[3],
+                                             const float pos_limit[3]);
 /* .with(child) -- node.rs:400; consumes both, returns b */
 sdfhost_builder* sdfhost_with(sdfhost_builder* b, sdfhost_builder* child);
 /* .transform(Transform{translation, rotation(x,y,z,w), scale}) -- node.rs:405; consumes b */

@@ -67,6 +67,7 @@ inline float rust_min(float a, float b) { return std::fmin(a, b); }
 
 // SSE _mm_max_ps(a, b) = a > b ? a : b  (glam Vec4::max, faux_shader.rs:57).
 inline float sse_max(float a, float b) { return a > b ? a : b; }
+inline float sse_min(float a, float b) { return a < b ? a : b; }   // _mm_min_ps: second operand on NaN
 
 // obb.rs:37-41 CmpFloat::cmp + Iterator::max (last of equal maxima wins).
 inline float cmpfloat_max(float acc, float x) {
@@ -119,11 +120,30 @@ bool prim_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, V4 p, float* out
     }
 }
 
-// faux_shader.rs:69-82 (union only; the clone op is a "next" row)
-bool downtree_dispatch(uint32_t code, const SdfOpSpecificBlock&, V4 p, V4 out[2]) {
+// faux_shader.rs:69-82.  Clone (op 1): [p - d * clamp(round(p / d), lo, hi), ZERO], per lane
+// of the Vec4 (d.w = lo.w = hi.w = 0, so the w lane stays 1: 1/0 = inf, clamp to 0, 0*0 = 0).
+// glam's round / clamp are restated as roundf (half away from zero) and max-then-min; nothing
+// the state machine returns depends on these two points, because uptree op 1 discards the
+// value computed below a one-slot clone (see uptree_dispatch).
+bool downtree_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, V4 p, V4 out[2]) {
     if (code == SDF_OP_UNION) {
         out[0] = p;
         out[1] = p;
+        return true;
+    }
+    if (code == SDF_OP_CAA_CLONE) {
+        const float* d = sp.vec4s[0].v;
+        const float* lo = sp.vec4s[1].v;
+        const float* hi = sp.vec4s[2].v;
+        const float in[4] = {p.x, p.y, p.z, p.w};
+        float o[4];
+        for (int k = 0; k < 4; ++k) {
+            float q = std::round(in[k] / d[k]);
+            q = sse_min(sse_max(q, lo[k]), hi[k]);
+            o[k] = in[k] - d[k] * q;
+        }
+        out[0] = V4{o[0], o[1], o[2], o[3]};
+        out[1] = V4{0, 0, 0, 0};
         return true;
     }
     return false;
@@ -133,9 +153,16 @@ struct DI { float d; uint32_t id; };
 
 // faux_shader.rs:84-94 with the index carried: min(l, r) is
 // `if l < r {l} else {r}` so ties and NaN-left go right.
+// Clone (op 1, :90) returns right_dist.  A one-slot node only ever fills branch_dists[0], so
+// the right one is still the +inf the frame was initialised with (:177): as written, a clone
+// subtree contributes +inf to its parent (SURVEY A-6).  Restated, not repaired.
 bool uptree_dispatch(uint32_t code, DI l, DI r, DI* out) {
     if (code == SDF_OP_UNION) {
         *out = (l.d < r.d) ? l : r;
+        return true;
+    }
+    if (code == SDF_OP_CAA_CLONE) {
+        *out = r;
         return true;
     }
     return false;
@@ -155,6 +182,7 @@ struct Tree {
     std::vector<uint32_t> prim_id;   // pre-order ordinal of each primitive block
     std::vector<uint32_t> prim_node; // inverse
     std::vector<int32_t> parent;
+    std::vector<uint8_t> dead;       // node lies in a clone subtree: its value never reaches the root
     uint32_t max_level;
 };
 
@@ -164,6 +192,7 @@ int build_tree(Tree& t, const SdfOperationBlock* dt, const SdfOperationUptreeBlo
     t.prim_id.assign(n, SDF_NO_PRIM);
     t.parent.assign(n, -1);
     t.prim_node.clear();
+    t.dead.assign(n, 0);
     t.max_level = 0;
     std::vector<int32_t> at_level(258, -1);
     for (uint32_t i = 0; i < n; ++i) {
@@ -172,6 +201,8 @@ int build_tree(Tree& t, const SdfOperationBlock* dt, const SdfOperationUptreeBlo
         if (lv > t.max_level) t.max_level = lv;
         t.parent[i] = (lv >= 2) ? at_level[lv - 1] : -1;
         at_level[lv] = (int32_t)i;
+        if ((!dt[i].is_primitive && dt[i].op_code == SDF_OP_CAA_CLONE) || (t.parent[i] >= 0 && t.dead[t.parent[i]]))
+            t.dead[i] = 1;
         if (dt[i].is_primitive) {
             t.prim_id[i] = (uint32_t)t.prim_node.size();
             t.prim_node.push_back(i);
@@ -306,6 +337,7 @@ struct Tuned {
     }
     void visit(uint32_t i, V4 p) {
         const SdfOperationBlock& b = t.dt[i];
+        if (t.dead[i]) return;   // clone subtree: +inf as written
         if (b.is_primitive) { leaf(i, p); return; }
         V4 pc = mat_mul(b.bounding_box.trans_inverse, p);
         uint32_t l = i + 1;
@@ -399,14 +431,17 @@ int oracle_knn(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, u
     int rc = build_tree(t, dt, ut, n);
     if (rc) return rc;
     return parallel_for(npts, threads, [&](size_t a, size_t b) -> int {
-        std::vector<DI> all(t.prim_node.size());
+        std::vector<DI> all;
+        all.reserve(t.prim_node.size());
         for (size_t i = a; i < b; ++i) {
             V4 p{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
+            all.clear();
             for (size_t j = 0; j < t.prim_node.size(); ++j) {
+                if (t.dead[t.prim_node[j]]) continue;   // below a clone: never reaches the root (uptree_dispatch)
                 float d;
                 int e = eval_leaf(t, t.prim_node[j], p, &d);
                 if (e) return e;
-                all[j] = DI{d, (uint32_t)j};
+                all.push_back(DI{d, (uint32_t)j});
             }
             size_t kk = std::min<size_t>(k, all.size());
             std::partial_sort(all.begin(), all.begin() + (long)kk, all.end(), better);

@@ -158,6 +158,7 @@ HOST_SYMBOLS = {
     "sdfhost_primitive_sphere": (_vp, [_f, C.POINTER(HostOptions)]),
     "sdfhost_primitive_box": (_vp, [_f, _f, _f, C.POINTER(HostOptions)]),
     "sdfhost_operation_union": (_vp, [_vp, _f]),
+    "sdfhost_operation_caa_clone": (_vp, [_vp, _fp, _fp, _fp]),
     "sdfhost_with": (_vp, [_vp, _vp]),
     "sdfhost_transform": (_vp, [_vp, _fp, _fp, _fp]),
     "sdfhost_finalize": (_vp, [_vp]),

@@ -27,6 +27,8 @@ struct Ctx {
     uint32_t bounds;
     std::vector<uint32_t> prim_id;
     std::vector<uint32_t> child0, child1;  // REF_NONE if absent (node indices)
+    std::vector<uint8_t> dead;             // node lies in a clone subtree (evaluates to +inf as written)
+    std::vector<uint32_t> live;            // primitives below the node that are not dead
     CompactTree* out;
     std::string* err;
     uint32_t max_inner_depth = 0;
@@ -118,12 +120,18 @@ void fill_obb(const SdfBoundingBoxBlock& bb, float fi[12], float sc[3]) {
 // Returns the reference of node i in the compact tree and its box / depth.
 uint32_t emit(Ctx& c, uint32_t i, Box3* box, uint32_t* depth) {
     const SdfOperationBlock& b = c.dt[i];
+    if (c.live[i] == 0) {   // clone subtree (or a union of nothing but those): +inf, not resident
+        *depth = 0;
+        return REF_NONE;
+    }
     if (b.is_primitive) {
         *depth = 0;
         if (c.bounds == SDFGPU_BOUNDS_AABB) leaf_aabb(b, box);
         return REF_LEAF | c.prim_id[i];
     }
     uint32_t k0 = c.child0[i], k1 = c.child1[i];
+    if (k1 != REF_NONE && c.live[k1] == 0) k1 = REF_NONE;
+    if (k0 != REF_NONE && c.live[k0] == 0) { k0 = k1; k1 = REF_NONE; }
     if (k1 == REF_NONE) return emit(c, k0, box, depth);  // 1-slot union: identity pass-through
     uint32_t self = 0;
     if (c.bounds == SDFGPU_BOUNDS_OBB) {
@@ -306,8 +314,13 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     // ---- structure: levels, len, child counts, op codes ----
     if (dt[0].level != 1) return fail(err, SDFGPU_ERR_BAD_TREE, "root level is %u, expected 1", dt[0].level);
     if (dt[0].len != n - 1) return fail(err, SDFGPU_ERR_BAD_TREE, "root len %u does not span buffer_len %u", dt[0].len, n);
-    uint32_t n_prims = 0, n_inner = 0, max_level = 0;
+    uint32_t n_prims = 0, n_inner = 0, max_level = 0, max_level_live = 0;
     bool identity_inner = true, rigid = true, exact_rows = true;
+    // A clone node (op 1) evaluates to +inf as the flat query is written: uptree op 1 returns
+    // the RIGHT branch distance (faux_shader.rs:90) and a one-slot node only fills the left one
+    // (:162,177).  Its whole subtree is therefore "dead": validated, numbered, never resident.
+    c.dead.assign(n, 0);
+    uint32_t dead_end = 0;
     float margin_T = 0.f;
     for (uint32_t i = 0; i < n; ++i) {
         if (dt[i].level == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u has level 0", i);
@@ -319,6 +332,10 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         if (b.is_primitive > 1 || b.parent_is_union > 1) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: bool field is not 0/1", i);
         if ((uint64_t)i + b.len >= n) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: len %u runs past the buffer", i, b.len);
         max_level = std::max(max_level, b.level);
+        if (!b.is_primitive && b.op_code == SDF_OP_CAA_CLONE) dead_end = std::max(dead_end, i + b.len + 1u);
+        const bool dead = i < dead_end;
+        c.dead[i] = dead ? 1 : 0;
+        if (!dead) max_level_live = std::max(max_level_live, b.level);
         const float* ti = b.bounding_box.trans_inverse.m;
         if (!finite16(ti)) return fail(err, SDFGPU_ERR_NON_FINITE, "node %u: non-finite trans_inverse", i);
         if (b.is_primitive) {
@@ -335,15 +352,15 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             } else {
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported primitive op code: %u (node %u)", b.op_code, i);
             }
-            if (!bottom_row_exact(ti)) exact_rows = false;
-            if (!rigid3(ti, 1e-4)) rigid = false;
+            if (!dead && !bottom_row_exact(ti)) exact_rows = false;
+            if (!dead && !rigid3(ti, 1e-4)) rigid = false;
             c.prim_id[i] = n_prims++;
         } else {
-            if (b.op_code != SDF_OP_UNION)
+            if (b.op_code != SDF_OP_UNION && b.op_code != SDF_OP_CAA_CLONE)
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported downtree op code: %u (node %u)", b.op_code, i);
             if (b.len == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "operation node %u has no children", i);
-            if (!is_identity(ti)) identity_inner = false;
-            ++n_inner;
+            if (!dead && !is_identity(ti)) identity_inner = false;
+            if (!dead) ++n_inner;
             uint32_t end = i + b.len, k = i + 1, cnt = 0;
             while (k <= end) {
                 if (dt[k].level != b.level + 1)
@@ -356,7 +373,17 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 ++cnt;
                 k += 1 + dt[k].len;
             }
+            if (b.op_code == SDF_OP_CAA_CLONE && cnt != 1)
+                return fail(err, SDFGPU_ERR_UNSUPPORTED_OP,
+                            "clone node %u has %u slots; the crate builds exactly one (elements.rs:222)", i, cnt);
         }
+    }
+    // live primitives below every node (children follow their parent in pre-order)
+    c.live.assign(n, 0);
+    for (uint32_t i = n; i-- > 0;) {
+        if (dt[i].is_primitive) c.live[i] = c.dead[i] ? 0u : 1u;
+        else c.live[i] = (c.child0[i] != REF_NONE ? c.live[c.child0[i]] : 0u) + (c.child1[i] != REF_NONE ? c.live[c.child1[i]] : 0u);
+        if (c.dead[i]) c.live[i] = 0;
     }
     // ---- the uptree buffer must be the post-order of the same tree ----
     {
@@ -386,18 +413,20 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 return fail(err, SDFGPU_ERR_BAD_TREE, "uptree block %u does not match downtree node %u", j, post[j]);
         }
     }
-    if (max_level - 1 > 63) return fail(err, SDFGPU_ERR_TOO_DEEP, "tree depth %u exceeds the 64-entry wave stack", max_level);
+    if (max_level_live > 64) return fail(err, SDFGPU_ERR_TOO_DEEP, "tree depth %u exceeds the 64-entry wave stack", max_level_live);
 
     if (!identity_inner || !exact_rows) {
         // General path: no pruning, the literal per-level point chain.
         if (bounds == SDFGPU_BOUNDS_AABB || bounds == SDFGPU_BOUNDS_OBB || bounds == SDFGPU_BOUNDS_BVH)
             return fail(err, SDFGPU_ERR_BAD_TREE,
                         "pruned bounds need identity internal trans_inverse and affine leaf rows; use AUTO or NONE");
-        if (max_level > GEN_MAX_LEVELS)
-            return fail(err, SDFGPU_ERR_TOO_DEEP, "general path holds %u levels, tree has %u", GEN_MAX_LEVELS, max_level);
-        out->gen.resize(n);
+        if (max_level_live > GEN_MAX_LEVELS)
+            return fail(err, SDFGPU_ERR_TOO_DEEP, "general path holds %u levels, tree has %u", GEN_MAX_LEVELS, max_level_live);
+        out->gen.reserve(n);
         for (uint32_t i = 0; i < n; ++i) {
-            GpuGenNode& g = out->gen[i];
+            if (c.dead[i]) continue;   // clone subtrees contribute +inf: left out of the walk
+            out->gen.emplace_back();
+            GpuGenNode& g = out->gen.back();
             std::memset(&g, 0, sizeof g);
             std::memcpy(g.m, dt[i].bounding_box.trans_inverse.m, 64);
             g.is_leaf = dt[i].is_primitive;
@@ -418,7 +447,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         gi.identity_inner = identity_inner ? 1 : 0;
         gi.rigid_leaves = rigid ? 1 : 0;
         gi.device_bytes = out->gen.size() * sizeof(GpuGenNode);
-        out->stack_depth = max_level + 1;
+        out->stack_depth = max_level_live + 1;
         return SDFGPU_OK;
     }
 
@@ -463,21 +492,24 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     Box3 root{};
     uint32_t depth = 0;
     if (mode == SDFGPU_BOUNDS_BVH) {
-        std::vector<PrimBox> prims(n_prims);
+        std::vector<PrimBox> prims;
+        prims.reserve(n_prims);
         for (uint32_t i = 0; i < n; ++i) {
-            if (!dt[i].is_primitive) continue;
-            PrimBox& q = prims[c.prim_id[i]];
+            if (!dt[i].is_primitive || c.dead[i]) continue;
+            prims.emplace_back();
+            PrimBox& q = prims.back();
             q.id = c.prim_id[i];
             if (!leaf_aabb(dt[i], &q.b)) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u: singular transform", i);
             for (int a = 0; a < 3; ++a) q.c[a] = 0.5 * (q.b.lo[a] + q.b.hi[a]);
         }
         // depth budget: balanced depth + slack, never beyond the 64-entry wave stack
+        const uint32_t n_live = (uint32_t)prims.size();
         uint32_t lg = 0;
-        while ((1ull << lg) < n_prims) ++lg;
+        while ((1ull << lg) < n_live) ++lg;
         uint32_t slack = 8;
         if (const char* e = std::getenv("SDFGPU_BVH_SLACK")) slack = (uint32_t)std::max(0, std::atoi(e));
         const uint32_t budget = std::min(64u, std::max(1u, lg + slack));
-        out->root_ref = build_sah(prims, 0, n_prims, budget, *out, &root, &depth);
+        out->root_ref = n_live ? build_sah(prims, 0, n_live, budget, *out, &root, &depth) : REF_NONE;
         if (depth > budget) return fail(err, SDFGPU_ERR_TOO_DEEP, "built hierarchy is %u levels deep (budget %u)", depth, budget);
     } else {
         out->root_ref = emit(c, 0, &root, &depth);
@@ -499,7 +531,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     {
         Box3 sb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
         for (uint32_t i = 0; i < n; ++i) {
-            if (!dt[i].is_primitive) continue;
+            if (!dt[i].is_primitive || c.dead[i]) continue;
             Box3 lb{};
             if (!leaf_aabb(dt[i], &lb)) continue;
             for (int a = 0; a < 3; ++a) { sb.lo[a] = std::min(sb.lo[a], lb.lo[a]); sb.hi[a] = std::max(sb.hi[a], lb.hi[a]); }

@@ -70,6 +70,18 @@ sdfhost_builder* sdfhost_operation_union(sdfhost_builder* b, float smooth_radius
     });
 }
 
+sdfhost_builder* sdfhost_operation_caa_clone(sdfhost_builder* b, const float displacement[3], const float neg_limit[3],
+                                             const float pos_limit[3]) {
+    if (!b) return nullptr;
+    if (!displacement || !neg_limit || !pos_limit) { delete b; g_err = "null argument"; return nullptr; }
+    return guard([&]() -> sdfhost_builder* {
+        std::unique_ptr<sdfhost_builder> own(b);
+        return new sdfhost_builder{std::move(own->b).operation(std::make_unique<SdfCaaClone>(
+            Vec3(displacement[0], displacement[1], displacement[2]), Vec3(neg_limit[0], neg_limit[1], neg_limit[2]),
+            Vec3(pos_limit[0], pos_limit[1], pos_limit[2])))};
+    });
+}
+
 sdfhost_builder* sdfhost_with(sdfhost_builder* b, sdfhost_builder* child) {
     if (!b || !child) { delete b; delete child; g_err = "null builder"; return nullptr; }
     return guard([&]() -> sdfhost_builder* {

@@ -422,6 +422,39 @@ ExpandedSdfNode SdfUnion::expand(const SdfNode& node, const BuildOptions& o) con
     return union_recurse(*this, node, all, o);
 }
 
+// ---------------------------------------------------------- SdfCaaClone ----
+// elements.rs:224-229
+SdfBoundingBox SdfCaaClone::get_bbox(const std::vector<SdfBoundingBox>&, const BuildOptions&) const {
+    const Vec3 c((neg_limit.x + pos_limit.x) / 2.f * displacement.x, (neg_limit.y + pos_limit.y) / 2.f * displacement.y,
+                 (neg_limit.z + pos_limit.z) / 2.f * displacement.z);
+    const Vec3 sc((pos_limit.x - neg_limit.x) * displacement.x, (pos_limit.y - neg_limit.y) * displacement.y,
+                  (pos_limit.z - neg_limit.z) * displacement.z);
+    return SdfBoundingBox::from_transform(Transform::from_translation(c).with_scale(sc));
+}
+
+// elements.rs:234-241 (Rust `%` on f32 is fmod: the result takes the sign of the dividend)
+Vec3 SdfCaaClone::downtree_transform(Vec3 p) const {
+    const Vec3 l(p.x - displacement.x / 2.0f, p.y - displacement.y / 2.0f, p.z - displacement.z / 2.0f);
+    return Vec3(std::fmod(l.x, displacement.x), std::fmod(l.y, displacement.y), std::fmod(l.z, displacement.z));
+}
+
+// elements.rs:252-258
+SdfOpSpecificBlock SdfCaaClone::get_dt_specific_block() const {
+    SdfOpSpecificBlock r;
+    std::memset(&r, 0, sizeof r);
+    const Vec3* src[3] = {&displacement, &neg_limit, &pos_limit};
+    for (int k = 0; k < 3; ++k) {
+        r.vec4s[k].v[0] = src[k]->x; r.vec4s[k].v[1] = src[k]->y; r.vec4s[k].v[2] = src[k]->z; r.vec4s[k].v[3] = 0.f;
+    }
+    return r;
+}
+
+// elements.rs:260-262
+ExpandedSdfNode SdfCaaClone::expand(const SdfNode& node, const BuildOptions& o) const {
+    if (node.slots.empty()) throw std::logic_error("SdfCaaClone::expand: slot 0 is empty");   // .get(0).unwrap()
+    return ExpandedSdfNode::simple_operation(node.slots[0].expanded(o), clone());
+}
+
 // ------------------------------------------------------ ExpandedSdfNode ----
 
 ExpandedSdfNode ExpandedSdfNode::null() { return ExpandedSdfNode(); }

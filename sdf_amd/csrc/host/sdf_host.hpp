@@ -137,6 +137,23 @@ struct SdfUnion : SdfElement {
     ExpandedSdfNode expand(const SdfNode& node, const BuildOptions& o) const override;
 };
 
+// elements.rs:215-262: continuous, axis-aligned clone (lattice repetition of its one slot).
+// Carried through the builder, the recursive query and make_buffer exactly as in the crate;
+// NOTE what the flat query makes of it (faux_shader.rs:90 returns `right_dist`, and a one-slot
+// node only ever fills the left one): a clone subtree evaluates to +inf there (SURVEY A-6).
+struct SdfCaaClone : SdfElement {
+    Vec3 displacement, neg_limit, pos_limit;
+    SdfCaaClone(Vec3 d, Vec3 lo, Vec3 hi) : displacement(d), neg_limit(lo), pos_limit(hi) {}
+    SdfElementInfo get_info() const override { return SdfElementInfo::strict_info(SDF_OP_CAA_CLONE, 0, 1); }
+    SdfBoundingBox get_bbox(const std::vector<SdfBoundingBox>& slots, const BuildOptions& o) const override;
+    Vec3 downtree_transform(Vec3 p) const override;
+    std::unique_ptr<SdfElement> clone() const override {
+        return std::make_unique<SdfCaaClone>(displacement, neg_limit, pos_limit);
+    }
+    SdfOpSpecificBlock get_dt_specific_block() const override;
+    ExpandedSdfNode expand(const SdfNode& node, const BuildOptions& o) const override;
+};
+
 // component.rs:80-96
 struct SdfTreeBuffer {
     std::vector<SdfOperationBlock> downtree_buffer;

@@ -125,6 +125,15 @@ class SdfUnion:
         self.smooth_radius = float(smooth_radius)
 
 
+class SdfCaaClone:
+    """elements.rs:215-262 (operation op 1, one slot): lattice repetition of its child."""
+
+    def __init__(self, displacement, neg_limit, pos_limit):
+        self.displacement = np.asarray(displacement, np.float32).reshape(3)
+        self.neg_limit = np.asarray(neg_limit, np.float32).reshape(3)
+        self.pos_limit = np.asarray(pos_limit, np.float32).reshape(3)
+
+
 class SdfTreeBuffer:
     """component.rs:80-96: downtree_buffer / uptree_buffer / buffer_len."""
 
@@ -247,9 +256,13 @@ class SdfBuilder:
         return SdfBuilder(h, opts)
 
     def operation(self, op):
-        if not isinstance(op, SdfUnion):
+        if isinstance(op, SdfCaaClone):
+            h = _ffi.load_library().sdfhost_operation_caa_clone(
+                self._take(), _ffi.fptr(op.displacement), _ffi.fptr(op.neg_limit), _ffi.fptr(op.pos_limit))
+        elif isinstance(op, SdfUnion):
+            h = _ffi.load_library().sdfhost_operation_union(self._take(), op.smooth_radius)
+        else:
             raise SdfError("unsupported operation")
-        h = _ffi.load_library().sdfhost_operation_union(self._take(), op.smooth_radius)
         if not h:
             raise SdfError(_host_err())
         return SdfBuilder(h, self._opts)

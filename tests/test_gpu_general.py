@@ -93,3 +93,58 @@ def test_box_bounds_match_the_reference_formulas(gpu):
     lo, hi = gpu.box_bounds(blk, pts)
     lo0, hi0 = O.bounds(odd, 5, pts)
     assert np.array_equal(bits(lo), bits(lo0)) and np.array_equal(bits(hi), bits(hi0))
+
+
+# ---- clone op (faux_shader.rs:75-78,90): a clone subtree is +inf as written ----
+
+def _clone_mix(n_live=40, n_clones=6, seed=21):
+    rng = np.random.default_rng(seed)
+    L = 25.0
+
+    def prim():
+        e = S.SdfSphere(float(rng.uniform(0.5, 2.0))) if rng.random() < 0.5 else S.SdfBox(tuple(float(v) for v in rng.uniform(0.5, 2.0, 3)))
+        return S.SdfBuilder.primitive(e).transform(S.Transform.from_translation(tuple(float(v) for v in rng.uniform(-L, L, 3))))
+
+    parts = [prim() for _ in range(n_live)]
+    for _ in range(n_clones):
+        parts.insert(int(rng.integers(0, len(parts))),
+                     prim().operation(S.SdfCaaClone((6, 6, 6), (-2, -2, -2), (2, 2, 2))))
+    b = parts[0].operation(S.SdfUnion(0.0))
+    for x in parts[1:]:
+        b = b.with_(x)
+    return b.finalize().expanded().make_buffer(), L
+
+
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AUTO, S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE, S.BOUNDS_BVH])
+def test_clone_subtrees_are_infinite_on_the_gpu_too(gpu, bounds):
+    from conftest import make_points
+    buf, L = _clone_mix()
+    pts = make_points(4000, L, 4)
+    d0, i0 = O.nearest(buf, pts, mode=O.MODE_EXHAUSTIVE, threads=8)
+    gpu.upload_tree(buf, bounds=bounds)
+    d, i = gpu.nearest(pts)
+    assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+    dk, ik = gpu.knn(pts[:1500], 8)
+    dk0, ik0 = O.knn(buf, pts[:1500], 8, threads=8)
+    assert np.array_equal(bits(dk), bits(dk0)) and np.array_equal(ik, ik0)
+    w, h = 96, 64
+    cam = S.camera_look_at((0.3 * L, 0.2 * L, -2.5 * L), (0, 0, 0), (0, 1, 0), 0.8, w, h)
+    mp = S.march_params(max_steps=96, eps_hit=1e-3, t_min=0.0, t_max=8 * L, normal_h=1e-4)
+    img = gpu.render(cam, w, h, mp)
+    ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
+    assert ref["hit"].sum() > 0
+    for k in ("hit", "prim"):
+        assert np.array_equal(img[k], ref[k])
+    assert np.array_equal(bits(img["depth"]), bits(ref["depth"])) and np.array_equal(bits(img["normal"]), bits(ref["normal"]))
+
+
+def test_clone_only_tree_on_the_gpu(gpu):
+    from conftest import make_points
+    node = S.SdfBuilder.primitive(S.SdfSphere(2.0)).operation(S.SdfCaaClone((5, 5, 5), (0, 0, 0), (3, 3, 3))).finalize()
+    buf = node.expanded().make_buffer()
+    gpu.upload_tree(buf)
+    d, i = gpu.nearest(make_points(3000, 10.0, 2))
+    assert np.all(np.isinf(d)) and np.all(i == S.NO_PRIM)
+    cam = S.camera_look_at((0, 0, -20.0), (0, 0, 0), (0, 1, 0), 0.8, 32, 24)
+    mp = S.march_params(max_steps=16, eps_hit=1e-3, t_min=0.0, t_max=100.0, normal_h=1e-4)
+    assert gpu.render(cam, 32, 24, mp)["hit"].sum() == 0
