@@ -112,7 +112,7 @@ enum {
     SDF_PRIM_SPHERE = 0,   /* elements.rs:85-118: floats[0] = radius */
     SDF_PRIM_BOX = 2,      /* build-defined (SURVEY C-7): vec4s[0] = half extents, w = 0 */
     SDF_OP_UNION = 0,      /* elements.rs:157-212 */
-    SDF_OP_CAA_CLONE = 1   /* elements.rs:215-262 (not accepted by the GPU path yet) */
+    SDF_OP_CAA_CLONE = 1   /* elements.rs:215-262; a one-slot clone subtree is +inf in the flat query as written (faux_shader.rs:90) */
 };
 
 #define SDF_NO_PRIM 0xFFFFFFFFu
