@@ -131,8 +131,22 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    # the k = 1 query (faux_shader::nearest_neighbor itself) on the same points and tree
+    step1 = lambda: gpu.nearest_dev(pts.data_ptr(), n, d_out.data_ptr(), i_out.data_ptr(), stream)  # noqa: E731
+    step1()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(a.knn_steps):
+        step1()
+    barrier()
+    el1 = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([el1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el1 = float(t.item())
     out = {
         "metric": "kNN queries/s (k=8)", "value": n_total * a.knn_steps / el, "unit": "queries/s",
+        "nearest_k1": {"value": n_total * a.knn_steps / el1, "unit": "queries/s", "ms_per_step": el1 / a.knn_steps * 1e3},
         "ms_per_step": el / a.knn_steps * 1e3, "steps": a.knn_steps,
         "config": {"workload": wl.name, "n_points": n_total, "k": k, "n_prims": wl.n_prims, "seed": hex(wl.seed),
                    "tree_levels": int(info.max_level), "tree_bytes_hbm": int(info.device_bytes),
