@@ -303,7 +303,8 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         return SDFGPU_OK;
     }
     if (!dt || !ut) return fail(err, SDFGPU_ERR_INVALID_ARG, "null buffer pointer");
-    if (n > REF_INDEX) return fail(err, SDFGPU_ERR_TOO_LARGE, "buffer_len %u too large", n);
+    // resident records are addressed as base + (index << 6) with a 32-bit offset (kernels.hip, load_rec64)
+    if (n > (1u << 26)) return fail(err, SDFGPU_ERR_TOO_LARGE, "buffer_len %u exceeds 2^26 nodes", n);
 
     Ctx c;
     c.dt = dt; c.n = n; c.out = out; c.err = err;
