@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--bounds", default="auto", choices=["auto", "aabb", "obb", "none", "bvh"])
     ap.add_argument("--skip-ext", type=float, default=0.0, help="SDFGPU_OPT_SKIP_EXTENSION (<0: half the mean primitive size)")
+    ap.add_argument("--no-tile-order", action="store_true", help="SDFGPU_OPT_TILE_ORDER=0: tiles in raster order")
     ap.add_argument("--compaction", action="store_true", help="multi-pass march with ray compaction (SDFGPU_OPT_COMPACTION=1)")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="frames in flight (1 = strictly one after the other; 0 = default: 2 on one GPU, "
@@ -217,6 +218,7 @@ def main():
     info = gpu.upload_tree(buf, bounds=bounds)
     gpu.set_skip_extension(a.skip_ext)
     gpu.set_compaction(a.compaction)
+    gpu.set_tile_order(not a.no_tile_order)
 
     npix = w * h
     tiles = P.n_tiles(w, h)

@@ -175,7 +175,13 @@ typedef enum sdfgpu_option {
      * marching, 64 to a wavefront, between them; 0 (default): one pass.  (On the
      * 10k-primitive benchmark scene the late, sparse passes are latency bound
      * and the single pass is faster; see DESIGN.md.) */
-    SDFGPU_OPT_COMPACTION = 2
+    SDFGPU_OPT_COMPACTION = 2,
+    /* render: 1 (default): the march records how many steps each 8x8 tile took, and the
+     * next frame of the same size on the same stream starts its longest tiles first (the
+     * few tiles that run all max_steps then overlap the bulk of the frame instead of
+     * trailing it).  Frames of at least 1024 tiles, single-pass march only.  0: tiles in
+     * raster order. */
+    SDFGPU_OPT_TILE_ORDER = 3
 } sdfgpu_option;
 int sdfgpu_set_option(sdfgpu_ctx* ctx, int option, double value);
 

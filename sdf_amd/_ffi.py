@@ -55,7 +55,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_HIP, ERR_NO_TREE, ERR_LAYOUT, ERR_BAD_TREE = -1, -2, -3, -4, -5
 ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE = -6, -7, -8, -9, -10
 MAX_K = 16
-OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION = 0, 1, 2
+OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER = 0, 1, 2, 3
 
 
 class TreeInfo(C.Structure):

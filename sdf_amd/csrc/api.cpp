@@ -36,8 +36,17 @@ struct sdfgpu_ctx {
     // multi-pass march (ray compaction)
     // one scratch per stream that has rendered: frames in flight on different streams
     // must not share pass state
-    struct MarchScratch { hipStream_t stream; DevBuf buf; };
+    struct MarchScratch {
+        hipStream_t stream;
+        DevBuf buf;                 // pass state of the multi-pass march (compaction)
+        // longest-first tile order from the costs the previous frame on this stream recorded
+        DevBuf order;               // [cost | iota | sorted keys | order] x tiles, then the sort's temp storage
+        uint32_t order_tiles = 0;   // tile count the buffers are laid out for
+        uint64_t order_sig = 0;     // frame geometry the recorded costs belong to
+        bool order_valid = false;
+    };
     std::vector<MarchScratch> march;
+    bool tile_order = true;         // SDFGPU_OPT_TILE_ORDER
     bool compaction = false;
     std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
     bool reorder = true;
@@ -142,6 +151,16 @@ std::vector<uint32_t> default_pass_steps() {
     return {12, 20, 28, 40, 56, 80};
 }
 
+// Per-stream scratch of a context (at most 16 streams; nullptr beyond that).
+sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream) {
+    for (auto& m : c->march)
+        if (m.stream == stream) return &m;
+    if (c->march.size() >= 16) return nullptr;
+    c->march.emplace_back();
+    c->march.back().stream = stream;
+    return &c->march.back();
+}
+
 int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t max_steps, RenderScratch* rs,
                 std::vector<uint32_t>* bounds) {
     bounds->clear();
@@ -154,14 +173,9 @@ int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t
     size_t sb = 0, cb = 0;
     const size_t total = render_scratch_bytes(tile_count, &sb, &cb);
     if (bounds->size() == 2) return SDFGPU_OK;   // single pass: no pass state
-    DevBuf* mb = nullptr;
-    for (auto& m : c->march)
-        if (m.stream == stream) mb = &m.buf;
-    if (!mb) {
-        if (c->march.size() >= 16) return set_err(c, SDFGPU_ERR_TOO_LARGE, "compaction: more than 16 distinct streams on one context");
-        c->march.push_back({stream, DevBuf()});
-        mb = &c->march.back().buf;
-    }
+    sdfgpu_ctx::MarchScratch* ms = stream_scratch(c, stream);
+    if (!ms) return set_err(c, SDFGPU_ERR_TOO_LARGE, "compaction: more than 16 distinct streams on one context");
+    DevBuf* mb = &ms->buf;
     int rc = reserve(c, *mb, total);
     if (rc) return rc;
     char* base = (char*)mb->p;
@@ -171,6 +185,54 @@ int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t
     rs->offsets = (uint32_t*)(base + 2 * sb + cb);
     rs->hdr[0] = (uint32_t*)(base + 2 * sb + 2 * cb);
     rs->hdr[1] = rs->hdr[0] + 4;
+    return SDFGPU_OK;
+}
+
+// One frame (or tile range) on `stream`: pass schedule, tile scheduling, launch.
+// Tile scheduling (SDFGPU_OPT_TILE_ORDER): the single-pass march records how many steps every
+// tile's wavefront ran; the next call on the SAME stream with the same frame geometry starts
+// the longest tiles first, so that the few 128-step tiles run beside the bulk of the frame
+// instead of after it.  A scheduling hint only: any order renders the same pixels.
+int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
+              const sdfgpu_march_params* mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
+              bool row_major, uint8_t* d_hit, float* d_depth, float* d_normal, uint32_t* d_prim) {
+    RenderScratch rs;
+    std::vector<uint32_t> pb;
+    int rc = march_setup(c, stream, tile_count, mp->max_steps, &rs, &pb);
+    if (rc) return rc;
+    sdfgpu_ctx::MarchScratch* ms = nullptr;
+    uint32_t *cost = nullptr, *iota = nullptr, *keys = nullptr, *order = nullptr;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    const bool single_pass = pb.size() == 2;
+    if (c->tile_order && single_pass && !c->tree.gen && tile_count >= 1024 && (ms = stream_scratch(c, stream))) {
+        temp_bytes = tile_sort_temp_bytes(tile_count);
+        const size_t arr = ((size_t)tile_count * sizeof(uint32_t) + 255) & ~(size_t)255;
+        if (ms->order_tiles != tile_count || !ms->order.p) {
+            if ((rc = reserve(c, ms->order, 4 * arr + temp_bytes + 256))) return rc;
+            ms->order_tiles = tile_count;
+            ms->order_valid = false;
+            HIP_TRY(c, launch_iota((uint32_t*)((char*)ms->order.p + arr), tile_count, stream));
+        }
+        char* base = (char*)ms->order.p;
+        cost = (uint32_t*)base;
+        iota = (uint32_t*)(base + arr);
+        keys = (uint32_t*)(base + 2 * arr);
+        order = (uint32_t*)(base + 3 * arr);
+        temp = base + 4 * arr;
+        const uint64_t sig = ((uint64_t)w << 48) ^ ((uint64_t)h << 32) ^ ((uint64_t)tile_first << 16) ^ ((uint64_t)tile_stride << 8) ^
+                             (uint64_t)tile_count ^ ((uint64_t)mp->max_steps << 40);
+        if (ms->order_sig != sig) ms->order_valid = false;
+        ms->order_sig = sig;
+        rs.tile_cost = cost;
+        rs.tile_order = ms->order_valid ? order : nullptr;
+    }
+    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, tile_first, tile_stride, tile_count, row_major, rs, pb.data(),
+                             (uint32_t)pb.size(), d_hit, d_depth, d_normal, d_prim, nullptr, stream));
+    if (cost) {
+        HIP_TRY(c, launch_tile_order(cost, iota, keys, order, tile_count, temp, temp_bytes, stream));
+        ms->order_valid = true;
+    }
     return SDFGPU_OK;
 }
 
@@ -230,8 +292,10 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
     for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats, &c->keys_a, &c->keys_b, &c->idx_a,
                       &c->idx_b, &c->sort_tmp})
         if (b->p) (void)hipFree(b->p);
-    for (auto& m : c->march)
+    for (auto& m : c->march) {
         if (m.buf.p) (void)hipFree(m.buf.p);
+        if (m.order.p) (void)hipFree(m.order.p);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -358,6 +422,10 @@ int sdfgpu_set_option(sdfgpu_ctx* c, int option, double value) {
         case SDFGPU_OPT_COMPACTION:
             c->compaction = value != 0.0;
             return SDFGPU_OK;
+        case SDFGPU_OPT_TILE_ORDER:
+            c->tile_order = value != 0.0;
+            for (auto& m : c->march) m.order_valid = false;
+            return SDFGPU_OK;
     }
     return set_err(c, SDFGPU_ERR_INVALID_ARG, "unknown option");
 }
@@ -428,12 +496,8 @@ int sdfgpu_render_tiles_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w,
     const uint64_t tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
     if (tile_stride == 0 || (uint64_t)tile_first + (uint64_t)(tile_count - 1) * tile_stride >= tiles)
         return set_err(c, SDFGPU_ERR_INVALID_ARG, "tile range outside the frame");
-    RenderScratch rs;
-    std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, (hipStream_t)stream, tile_count, mp->max_steps, &rs, &pb))) return rc;
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, tile_first, tile_stride, tile_count, false, rs, pb.data(),
-                             (uint32_t)pb.size(), d_hit, d_depth, d_normal, d_prim, nullptr, (hipStream_t)stream));
-    return SDFGPU_OK;
+    return render_on(c, (hipStream_t)stream, cam, w, h, mp, tile_first, tile_stride, tile_count, false, d_hit, d_depth,
+                     d_normal, d_prim);
 }
 
 int sdfgpu_render_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h, const sdfgpu_march_params* mp,
@@ -443,12 +507,7 @@ int sdfgpu_render_dev(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint3
     if ((rc = check_march(c, cam, w, h, mp))) return rc;
     if (!d_hit) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null hit buffer");
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
-    RenderScratch rs;
-    std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, (hipStream_t)stream, tiles, mp->max_steps, &rs, &pb))) return rc;
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(), d_hit,
-                             d_depth, d_normal, d_prim, nullptr, (hipStream_t)stream));
-    return SDFGPU_OK;
+    return render_on(c, (hipStream_t)stream, cam, w, h, mp, 0, 1, tiles, true, d_hit, d_depth, d_normal, d_prim);
 }
 
 int sdfgpu_untile_dev(sdfgpu_ctx* c, uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride,
@@ -480,12 +539,9 @@ int sdfgpu_render(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t 
         (rc = reserve(c, c->out_d, np * 4)))
         return rc;
     const uint32_t tiles = ((w + 7) / 8) * ((h + 7) / 8);
-    RenderScratch rs;
-    std::vector<uint32_t> pb;
-    if ((rc = march_setup(c, c->stream, tiles, mp->max_steps, &rs, &pb))) return rc;
-    HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(),
-                             (uint8_t*)c->out_a.p, (float*)c->out_b.p, (float*)c->out_c.p, (uint32_t*)c->out_d.p, nullptr,
-                             c->stream));
+    if ((rc = render_on(c, c->stream, cam, w, h, mp, 0, 1, tiles, true, (uint8_t*)c->out_a.p, (float*)c->out_b.p,
+                        (float*)c->out_c.p, (uint32_t*)c->out_d.p)))
+        return rc;
     HIP_TRY(c, hipMemcpyAsync(hit, c->out_a.p, np, hipMemcpyDeviceToHost, c->stream));
     if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->out_b.p, np * 4, hipMemcpyDeviceToHost, c->stream));
     if (normal) HIP_TRY(c, hipMemcpyAsync(normal, c->out_c.p, np * 12, hipMemcpyDeviceToHost, c->stream));

@@ -644,6 +644,8 @@ struct PassArgs {
     const uint32_t* in_hdr;           // {number of source waves, total survivors}
     RayState* out_state;
     uint32_t* out_counts;
+    const uint32_t* tile_order;       // first pass: wave w renders tile tile_order[w] (null: tile w)
+    uint32_t* tile_cost;              // first pass: min(steps the wave ran, 255) per tile (null: not recorded)
 };
 
 template <int MODE, bool COUNT, bool FIRST>
@@ -663,7 +665,12 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     bool alive;
     if constexpr (FIRST) {
         if (wave_id >= tile_count) return;
-        slot = wave_id * 64u + lane;
+        uint32_t tl = wave_id;
+        if (pa.tile_order) {   // longest tiles first; anything out of range falls back to the identity
+            tl = __builtin_amdgcn_readfirstlane(pa.tile_order[wave_id]);
+            tl = tl < tile_count ? tl : wave_id;
+        }
+        slot = tl * 64u + lane;
         alive = true;
     } else {
         // header / offsets are clamped to what the scratch can hold, so that even
@@ -723,7 +730,8 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     const float ext = T.skip_ext;
     WaveCounters wc;
 
-    for (uint32_t s = pa.step_begin; s < pa.step_end; ++s) {
+    uint32_t s = pa.step_begin;
+    for (; s < pa.step_end; ++s) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         if (alive) {
             px = ox + dx * t;
@@ -770,6 +778,12 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         }
     }
 
+    if constexpr (FIRST) {
+        if (pa.tile_cost && lane == 0) {
+            const uint32_t ran = s - pa.step_begin;
+            pa.tile_cost[slot >> 6] = ran < 255u ? ran : 255u;
+        }
+    }
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (hit) {
         const GpuLeaf* L = T.leaf + hit_prim;
@@ -1146,6 +1160,8 @@ static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam,
         pa.in_hdr = rs.hdr[k & 1];
         pa.out_state = (RayState*)rs.state[k & 1];
         pa.out_counts = rs.counts;
+        pa.tile_order = (n_bounds == 2 && !COUNT) ? rs.tile_order : nullptr;
+        pa.tile_cost = (n_bounds == 2 && !COUNT) ? rs.tile_cost : nullptr;
         if (k == 0)
             render_pass_kernel<MODE, COUNT, true><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
                                                                           row_major ? 1u : 0u, pa, hit, depth, normal, prim, st);

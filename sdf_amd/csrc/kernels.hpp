@@ -44,7 +44,15 @@ struct RenderScratch {
     uint32_t* counts = nullptr;
     uint32_t* offsets = nullptr;
     uint32_t* hdr[2] = {nullptr, nullptr};
+    // tile scheduling: wave w of the (single-pass) march renders tile tile_order[w] of the call's
+    // tile range; every wave records min(march steps it ran, 255) in tile_cost[its tile].  Either may be null.
+    const uint32_t* tile_order = nullptr;
+    uint32_t* tile_cost = nullptr;
 };
+size_t tile_sort_temp_bytes(uint32_t n);
+hipError_t launch_iota(uint32_t* v, uint32_t n, hipStream_t s);
+hipError_t launch_tile_order(const uint32_t* cost, const uint32_t* iota, uint32_t* keys_out, uint32_t* order_out,
+                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 size_t render_scratch_bytes(uint32_t tile_count, size_t* state_bytes, size_t* count_bytes);
 
 // pass_bounds: 0 = b[0] < ... < b[n-1] = max_steps (n >= 2; n == 2 is a single pass).

@@ -150,3 +150,51 @@ def test_config5_knn_10m_100k(gpu):
     finally:
         gpu.set_reorder(True)
     assert np.array_equal(bits(dr[::-1]), bits(d[:m])) and np.array_equal(ir[::-1], i[:m])
+
+
+def test_tile_scheduling_is_invisible(gpu):
+    # SDFGPU_OPT_TILE_ORDER: from the second frame of a size on, tiles start longest-first
+    # (costs recorded by the frame before); every frame must equal the raster-order frame
+    torch = pytest.importorskip("torch")
+    wl = W.CONFIGS[3]
+    w, h = wl.width, wl.height
+    cam, mp = W.camera(wl), W.march(wl)
+    gpu.upload_tree(_scene(3))
+    gpu.set_tile_order(False)
+    ref = gpu.render(cam, w, h, mp)
+    gpu.set_tile_order(True)
+    try:
+        for _ in range(3):
+            img = gpu.render(cam, w, h, mp)
+            for k in ("hit", "prim"):
+                assert np.array_equal(img[k], ref[k])
+            assert np.array_equal(bits(img["depth"]), bits(ref["depth"]))
+            assert np.array_equal(bits(img["normal"]), bits(ref["normal"]))
+        # a different camera on the same stream: the recorded costs are stale, the frame is still right
+        cam2 = S.camera_look_at((30.0, 10.0, -200.0), (0, 0, 0), (0, 1, 0), 0.7, w, h)
+        gpu.set_tile_order(False)
+        ref2 = gpu.render(cam2, w, h, mp)
+        gpu.set_tile_order(True)
+        gpu.render(cam, w, h, mp)
+        img2 = gpu.render(cam2, w, h, mp)
+        assert np.array_equal(img2["hit"], ref2["hit"]) and np.array_equal(img2["prim"], ref2["prim"])
+        assert np.array_equal(bits(img2["depth"]), bits(ref2["depth"]))
+        # tile shares (the multi-GPU path), twice in a row on one stream
+        tiles = P.n_tiles(w, h)
+        first, stride, cnt = P.rank_tiles(1, 4, tiles)
+        dev = torch.device("cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for _ in range(3):
+            t_hit = torch.zeros(cnt * 64, dtype=torch.uint8, device=dev)
+            t_depth = torch.zeros(cnt * 64, dtype=torch.float32, device=dev)
+            t_normal = torch.zeros(cnt * 64 * 3, dtype=torch.float32, device=dev)
+            t_prim = torch.zeros(cnt * 64, dtype=torch.int32, device=dev)
+            gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, t_hit.data_ptr(), t_depth.data_ptr(),
+                                 t_normal.data_ptr(), t_prim.data_ptr(), stream)
+            torch.cuda.synchronize()
+            outs.append((t_hit.cpu(), t_depth.cpu().view(torch.int32), t_normal.cpu().view(torch.int32), t_prim.cpu()))
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    finally:
+        gpu.set_tile_order(True)
