@@ -411,6 +411,9 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 // Warm the scalar cache with both children's records while the box tests run: the
 // record of whichever child is visited next then costs a cache hit (~100 cycles)
 // instead of an L2 round trip (~210).  The dword lands in the record's padding.
+#ifdef SDFGPU_NO_PREFETCH
+#define SDFGPU_WALK_PREFETCH ""
+#else
 #define SDFGPU_WALK_PREFETCH                                                                           \
     "s_lshl_b32 %[t0], s92, 6\n\t"                                                                     \
     "s_bitcmp1_b32 s92, 31\n\t"                                                                        \
@@ -420,6 +423,7 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_bitcmp1_b32 s93, 31\n\t"                                                                        \
     "s_cselect_b64 %[m0], %[lbase], %[base]\n\t"                                                       \
     "s_load_dword s95, %[m0], %[t1]\n\t"
+#endif
 
 template <bool TRACK>
 __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& refs, float& lb, float thr, float px,
