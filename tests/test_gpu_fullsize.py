@@ -198,3 +198,33 @@ def test_tile_scheduling_is_invisible(gpu):
             assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
     finally:
         gpu.set_tile_order(True)
+
+
+def test_tile_scheduling_with_frames_in_flight_on_two_streams(gpu):
+    # the recorded costs and the order belong to (context, stream): two streams rendering
+    # different cameras concurrently, frame after frame, never see each other's state
+    torch = pytest.importorskip("torch")
+    wl = W.CONFIGS[3]
+    w, h = wl.width, wl.height
+    mp = W.march(wl)
+    cams = [W.camera(wl), S.camera_look_at((60.0, -20.0, -220.0), (0, 0, 0), (0, 1, 0), 0.75, w, h)]
+    gpu.upload_tree(_scene(3))
+    gpu.set_tile_order(False)
+    refs = [gpu.render(c, w, h, mp) for c in cams]
+    gpu.set_tile_order(True)
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(dev) for _ in cams]
+    outs = [(torch.empty(w * h, dtype=torch.uint8, device=dev), torch.empty(w * h, dtype=torch.float32, device=dev),
+             torch.empty(w * h * 3, dtype=torch.float32, device=dev), torch.empty(w * h, dtype=torch.int32, device=dev))
+            for _ in cams]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for cam, st, o in zip(cams, streams, outs):
+            gpu.render_dev(cam, w, h, mp, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                           stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for o, ref in zip(outs, refs):
+            assert np.array_equal(o[0].cpu().numpy(), ref["hit"])
+            assert np.array_equal(o[3].cpu().numpy().view(np.uint32), ref["prim"])
+            assert np.array_equal(bits(o[1].cpu().numpy()), bits(ref["depth"]))
+            assert np.array_equal(bits(o[2].cpu().numpy().reshape(-1, 3)), bits(ref["normal"]))
