@@ -314,8 +314,8 @@ pop:
 //
 // Contract of the block: on entry `cur` is an internal/leaf reference or
 // REF_POP ("take the next pending subtree"); on exit `cur` is a leaf reference
-// to evaluate, or REF_NONE when the walk is over.  s[80:95] hold the node
-// record.  Hazards: no VALU-written SGPR is read by a VALU here (gfx950 needs
+// to evaluate, with that leaf's record in `rec`, or REF_NONE when the walk is
+// over.  s[80:95] hold the internal node's record, s96/s97 take the prefetches.  Hazards: no VALU-written SGPR is read by a VALU here (gfx950 needs
 // two wait states for that); lane masks go VALU->SALU->VALU, which interlocks.
 constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 
@@ -407,12 +407,19 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "v_readlane_b32 %[cur], %[refs], %[sp]\n\t"                                                        \
     "s_branch .Ltop%=\n"                                                                               \
     ".Lempty%=:\n\t"                                                                                   \
-    "s_mov_b32 %[cur], -1\n"                                                                           \
-    ".Ldone%=:\n\t"
+    "s_mov_b32 %[cur], -1\n\t"                                                                         \
+    "s_branch .Lexit%=\n"                                                                              \
+    ".Ldone%=:\n\t"                        /* leaf reference: fetch its record (bit 31 shifts out) */    \
+    "s_lshl_b32 %[t0], %[cur], 6\n\t"                                                                  \
+    "s_load_dwordx16 %[rec], %[lbase], %[t0]\n"                                                        \
+    ".Lexit%=:\n\t"                        /* nothing (prefetches included) may still be in flight */   \
+    "s_waitcnt lgkmcnt(0)\n\t"
 
 // Warm the scalar cache with both children's records while the box tests run: the
 // record of whichever child is visited next then costs a cache hit (~100 cycles)
-// instead of an L2 round trip (~210).  The dword lands in the record's padding.
+// instead of an L2 round trip (~210).  The dwords land in two scratch SGPRs; the block
+// waits for every outstanding scalar load before it ends, so none can land later in a
+// register the compiler has meanwhile given to something else.
 #ifdef SDFGPU_NO_PREFETCH
 #define SDFGPU_WALK_PREFETCH ""
 #else
@@ -420,27 +427,27 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_lshl_b32 %[t0], s92, 6\n\t"                                                                     \
     "s_bitcmp1_b32 s92, 31\n\t"                                                                        \
     "s_cselect_b64 %[t], %[lbase], %[base]\n\t"                                                        \
-    "s_load_dword s94, %[t], %[t0]\n\t"                                                                \
+    "s_load_dword s96, %[t], %[t0]\n\t"                                                                \
     "s_lshl_b32 %[t1], s93, 6\n\t"                                                                     \
     "s_bitcmp1_b32 s93, 31\n\t"                                                                        \
     "s_cselect_b64 %[m0], %[lbase], %[base]\n\t"                                                       \
-    "s_load_dword s95, %[m0], %[t1]\n\t"
+    "s_load_dword s97, %[m0], %[t1]\n\t"
 #endif
 
 template <bool TRACK>
 __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& refs, float& lb, float thr, float px,
                                              float py, float pz, unsigned long long drive, const GpuInner* base,
-                                             const GpuLeaf* lbase, uint32_t sa) {
+                                             const GpuLeaf* lbase, uint32_t sa, f32x16& rec) {
     unsigned long long m0, m1, t;
     uint32_t t0, t1;
     float a, b, c, d, k0, k1;
 #define SDFGPU_WALK_OPERANDS                                                                                          \
     : [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [m0] "=&s"(m0), [m1] "=&s"(m1), [t] "=&s"(t), \
       [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [k0] "=&v"(k0),          \
-      [k1] "=&v"(k1)                                                                                                  \
+      [k1] "=&v"(k1), [rec] "=&s"(rec)                                                                                \
     : [thr] "v"(thr), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [drive] "s"(drive), [base] "s"(base), [lbase] "s"(lbase), [sa] "v"(sa)      \
     : "vcc", "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",       \
-      "s91", "s92", "s93", "s94", "s95"
+      "s91", "s92", "s93", "s94", "s95", "s96", "s97"
     if constexpr (TRACK) {
         asm volatile(SDFGPU_WALK_ASM("v_min_f32 %[lb], %[lb], %[k0]\n\t", "v_min_f32 %[lb], %[lb], %[k1]\n\t",
                                      "v_min_f32 %[lb], %[lb], %[a]\n\t", SDFGPU_WALK_PREFETCH) SDFGPU_WALK_OPERANDS);
@@ -465,12 +472,12 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
     // LDS byte address of this lane's slot in stack level 0; level l is 256 bytes further
     const uint32_t sa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)stk + lane * 4u;
     for (;;) {
-        walk_advance<Acc::TRACKS>(cur, sp, refs, lb, thr, px, py, pz, drive, T.inner, T.leaf, sa);
+        f32x16 L;   // the leaf's record, fetched inside the block (undefined when the walk is over)
+        walk_advance<Acc::TRACKS>(cur, sp, refs, lb, thr, px, py, pz, drive, T.inner, T.leaf, sa, L);
         cur = __builtin_amdgcn_readfirstlane(cur);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (cur == REF_NONE) break;
         const uint32_t id = cur & REF_INDEX;
-        const f32x16 L = load_rec64(T.leaf, id);
         acc.offer(leaf_eval_rec(L, px, py, pz), id);
         thr = prune_threshold<MODE>(acc.radius(), mg, ext);
         cur = REF_POP;
