@@ -59,6 +59,11 @@ pub struct TreeInfo {
 pub const LAYOUT_GLAM_SSE2: u32 = 0;
 pub const BOUNDS_AUTO: u32 = 0;
 pub const NO_PRIM: u32 = 0xFFFF_FFFF;
+/// `sdfgpu_option` (none of them changes a result)
+pub const OPT_REORDER: i32 = 0;
+pub const OPT_SKIP_EXTENSION: i32 = 1;
+pub const OPT_COMPACTION: i32 = 2;
+pub const OPT_TILE_ORDER: i32 = 3;
 
 extern "C" {
     fn sdfgpu_create(device_id: c_int, out: *mut *mut Ctx) -> c_int;
