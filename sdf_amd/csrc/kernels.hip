@@ -49,10 +49,18 @@ __device__ __forceinline__ float prim_value(uint32_t kind, float p0, float p1, f
     return l + __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
 }
 
+// Per-lane evaluation of one leaf record (the march's seed, the normal taps): the whole 64-byte
+// line is requested at once, so that a box does not pay a second memory round trip for the
+// half extents its kind selects.
 __device__ __forceinline__ float leaf_eval(const GpuLeaf* __restrict__ L, float px, float py, float pz) {
-    float lx, ly, lz;
-    leaf_point(L->m, px, py, pz, lx, ly, lz);
-    return prim_value(L->kind, L->param[0], L->param[1], L->param[2], lx, ly, lz);
+    const float4* __restrict__ q = reinterpret_cast<const float4*>(L);
+    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+    float4 r3 = q[3];
+    asm volatile("" : "+v"(r3.y), "+v"(r3.z));   // keeps the compiler from sinking half of this load behind the kind test
+    const float lx = ((r0.x * px + r0.y * py) + r0.z * pz) + r0.w;
+    const float ly = ((r1.x * px + r1.y * py) + r1.z * pz) + r1.w;
+    const float lz = ((r2.x * px + r2.y * py) + r2.z * pz) + r2.w;
+    return prim_value(__builtin_bit_cast(uint32_t, r3.w), r3.x, r3.y, r3.z, lx, ly, lz);
 }
 
 // (distance, index) order of the reference's union combine composed over the
