@@ -172,9 +172,10 @@ typedef enum sdfgpu_option {
      * pays off in dense scenes with long grazing rays. */
     SDFGPU_OPT_SKIP_EXTENSION = 1,
     /* render: 1 cuts the march into passes and re-packs the rays still
-     * marching, 64 to a wavefront, between them; 0 (default): one pass.  (On the
-     * 10k-primitive benchmark scene the late, sparse passes are latency bound
-     * and the single pass is faster; see DESIGN.md.) */
+     * marching, 64 to a wavefront, between them (default schedule: two passes, the
+     * first 40 steps long; SDFGPU_PASS_STEPS="a,b,.." in the environment of
+     * sdfgpu_create sets another); 0 (default): one pass.  Trades the latency of one
+     * frame for throughput with frames in flight; see DESIGN.md. */
     SDFGPU_OPT_COMPACTION = 2,
     /* render: 1 (default): the march records how many steps each 8x8 tile took, and the
      * next frame of the same size on the same stream starts its longest tiles first (the

@@ -142,20 +142,25 @@ def test_grazing_camera_inside_the_scene(gpu):
 
 
 @pytest.mark.parametrize("max_steps", [0, 1, 11, 12, 13, 28, 57, 200])
-def test_ray_compaction_is_invisible(gpu, max_steps):
-    # the multi-pass march (SDFGPU_OPT_COMPACTION) re-packs survivors between passes;
-    # pass boundaries at 12/20/28/40/56/80 steps must not show in any output
-    n, w, h = 250, 121, 67
-    buf = S.random_scene_buffer(n, 0xBEEF)
-    L = S.default_extent(n)
-    cam = S.camera_look_at((0.2 * L, 0.1 * L, -1.2 * L), (0, 0, 0), (0, 1, 0), 1.0, w, h)
-    mp = S.march_params(max_steps=max_steps, eps_hit=1e-3, t_min=0.0, t_max=6 * L, normal_h=1e-4)
-    ref = O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8)
-    gpu.upload_tree(buf)
-    for on in (True, False):
-        gpu.set_compaction(on)
-        _compare(gpu.render(cam, w, h, mp), ref)
-    gpu.set_compaction(False)
+def test_ray_compaction_is_invisible(max_steps, monkeypatch):
+    # the multi-pass march (SDFGPU_OPT_COMPACTION) re-packs survivors between passes; pass
+    # boundaries -- here a six-pass schedule, read when the context is created -- must not show
+    # in any output
+    monkeypatch.setenv("SDFGPU_PASS_STEPS", "12,20,28,40,56,80")
+    g = S.SdfGpu(0)
+    try:
+        n, w, h = 250, 121, 67
+        buf = S.random_scene_buffer(n, 0xBEEF)
+        L = S.default_extent(n)
+        cam = S.camera_look_at((0.2 * L, 0.1 * L, -1.2 * L), (0, 0, 0), (0, 1, 0), 1.0, w, h)
+        mp = S.march_params(max_steps=max_steps, eps_hit=1e-3, t_min=0.0, t_max=6 * L, normal_h=1e-4)
+        ref = O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8)
+        g.upload_tree(buf)
+        for on in (True, False):
+            g.set_compaction(on)
+            _compare(g.render(cam, w, h, mp), ref)
+    finally:
+        g.close()
 
 
 def test_compaction_two_frames_in_flight(gpu):
