@@ -378,6 +378,9 @@ def main():
                 "kernel_ms_avg": k_avg,
                 "algorithmic_flops_per_launch": flops,
                 "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS,
+                # tools/ubench/issue_rates.hip: a SIMD retires one plain fp32 VALU instruction per ~2.6
+                # cycles with 8 waves resident, i.e. 60.5 Tflop/s of unfused operations chip-wide
+                "frac_of_measured_issue_peak": achieved / 60.5,
                 # the same flops over the pipelined frame time (frames in flight fill the drain)
                 "frac_at_throughput": flops / (ms * 1e-3) / 1e12 / VALU_PEAK_UNFUSED_TFLOPS,
                 "hbm": {"algorithmic_bytes_per_launch": bytes_alg,
