@@ -102,3 +102,31 @@ def test_w_not_one_is_rejected(gpu):
     with pytest.raises(S.SdfGpuError) as e:
         gpu.nearest(p)
     assert e.value.status == S._ffi.ERR_POINT_W
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_dense_nn_single_and_chain_on_the_gpu(gpu, chain):
+    # the crate's test_dense_nn_{single,chain}_{uni,dir} (node.rs:625-656) through the GPU path:
+    # one primitive under translate / rotate / both orders, bare or inside a one-slot union
+    import math
+    rng = np.random.default_rng(9)
+    for prim in (S.SdfSphere(1.0), S.SdfBox((0.7, 1.3, 2.1))):
+        for _ in range(6):
+            tl = S.Transform.from_translation(rng.uniform(-50, 50, 3))
+            rot = S.Transform.from_rotation(S.Quat.from_euler_xyz(*rng.uniform(0, 2 * math.pi, 3)))
+            TL, RO = np.linalg.inv(tl.compute_matrix()), np.linalg.inv(rot.compute_matrix())
+            pts = np.ones((64, 4), np.float32)
+            pts[:, :3] = rng.uniform(-50, 50, (64, 3))
+            for ts, inv in (([tl], TL), ([rot], RO), ([tl, rot], TL @ RO), ([rot, tl], RO @ TL)):
+                b = S.SdfBuilder.primitive(prim)
+                for t in ts:
+                    b = b.transform(t)
+                if chain:
+                    b = b.operation(S.SdfUnion(0.0))
+                buf = b.finalize().expanded().make_buffer()
+                gpu.upload_tree(buf)
+                d, i = gpu.nearest(pts)
+                d0, i0 = O.nearest(buf, pts, mode=O.MODE_FAUX)
+                assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+                gt = np.array([prim.distance_to((inv @ q.astype(np.float64))[:3]) for q in pts])
+                assert np.all(np.abs(d - gt) <= 4e-5 * np.maximum(1.0, np.abs(gt)))

@@ -223,3 +223,34 @@ def test_recursive_query_equals_the_flat_query(shape):
     assert np.array_equal(bits(got), bits(d0))
     prims = {node.nearest_neighbor(p[:3])[1] for p in pts[:300]}
     assert len(prims) > 3 and all(0 <= i < buf.n_prims for i in prims)
+
+
+def _dense_cases(rng):
+    import math
+    tl = S.Transform.from_translation(rng.uniform(-50, 50, 3))
+    rot = S.Transform.from_rotation(S.Quat.from_euler_xyz(*rng.uniform(0, 2 * math.pi, 3)))
+    TL, RO = np.linalg.inv(tl.compute_matrix()), np.linalg.inv(rot.compute_matrix())
+    return {"tlate": ([tl], TL), "rot": ([rot], RO), "tlate_rot": ([tl, rot], TL @ RO), "rot_tlate": ([rot, tl], RO @ TL)}
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_dense_nn_single_and_chain_through_the_recursive_query(chain):
+    # the crate's own tests (node.rs:625-656) call SdfNode::nearest_neighbor: single primitive under
+    # translate / rotate / both orders (do_dense_nn_single), and the same wrapped in a one-slot union
+    # (do_dense_nn_chain; with the C-3 fix the union does not re-base the point, so the chain case
+    # holds for translations too -- in the crate it fails for them)
+    rng = np.random.default_rng(7)
+    for prim in (S.SdfSphere(1.0), S.SdfBox((0.7, 1.3, 2.1))):
+        for _ in range(10):
+            p = rng.uniform(-50, 50, 3).astype(np.float32)
+            for name, (ts, inv) in _dense_cases(rng).items():
+                b = S.SdfBuilder.primitive(prim)
+                for t in ts:
+                    b = b.transform(t)
+                if chain:
+                    b = b.operation(S.SdfUnion(0.0))
+                node = b.finalize()
+                gt = prim.distance_to((inv @ np.append(p.astype(np.float64), 1.0))[:3])
+                got, idx = node.nearest_neighbor(p)
+                assert idx == 0
+                assert abs(got - gt) <= 4e-5 * max(1.0, abs(gt)), (name, chain, got, gt)
