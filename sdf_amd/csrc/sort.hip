@@ -72,6 +72,9 @@ hipError_t launch_morton_order(const float* pts, uint32_t n, const float lo[3], 
 // stream recorded: stable descending sort on the cost's bits [2, 8) (64 buckets of 4 march
 // steps; tiles of one bucket keep their spatial order, which keeps neighbours -- and their
 // scalar-cache lines -- together).
+#ifndef TILE_SORT_LO
+#define TILE_SORT_LO 2
+#endif
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) v[i] = i;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ v, uin
 size_t tile_sort_temp_bytes(uint32_t n) {
     size_t bytes = 0;
     uint32_t* k = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, k, k, k, k, (int)n, 2, 8, (hipStream_t)0);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, k, k, k, k, (int)n, TILE_SORT_LO, 8, (hipStream_t)0);
     return bytes;
 }
 
@@ -93,7 +96,7 @@ hipError_t launch_iota(uint32_t* v, uint32_t n, hipStream_t s) {
 hipError_t launch_tile_order(const uint32_t* cost, const uint32_t* iota, uint32_t* keys_out, uint32_t* order_out,
                              uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, cost, keys_out, iota, order_out, (int)n, 2, 8, s);
+    return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, cost, keys_out, iota, order_out, (int)n, TILE_SORT_LO, 8, s);
 }
 
 }  // namespace sdfgpu
