@@ -54,6 +54,21 @@ __global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) 
             REP8(asm volatile("v_pk_add_f32 %0, %4, %1 op_sel_hi:[1,0]\n v_pk_add_f32 %2, %4, %1 op_sel_hi:[1,0]\n v_pk_add_f32 %3, %4, %1 op_sel_hi:[1,0]\n v_pk_add_f32 %1, %4, %0 op_sel_hi:[1,0]"
                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "s"(sp));)
             a0 += (float)d0 + (float)d1 + (float)d2 + (float)d3;
+        } else if constexpr (KIND == 10) {  // the walk's box test of two children: 24 VALU + 2 compares, SGPR operands
+            float k0, k1, ta, tb, tc;
+            asm volatile(
+                "v_subrev_f32 %2, %8, %5\n v_subrev_f32 %3, %9, %6\n v_subrev_f32 %4, %10, %7\n"
+                "v_sub_f32 %2, |%2|, %9\n v_sub_f32 %3, |%3|, %10\n v_sub_f32 %4, |%4|, %8\n"
+                "v_max_f32 %2, 0, %2\n v_max_f32 %3, 0, %3\n v_max_f32 %4, 0, %4\n"
+                "v_mul_f32 %0, %2, %2\n v_fmac_f32 %0, %3, %3\n v_fmac_f32 %0, %4, %4\n"
+                "v_subrev_f32 %2, %10, %5\n v_subrev_f32 %3, %8, %6\n v_subrev_f32 %4, %9, %7\n"
+                "v_sub_f32 %2, |%2|, %8\n v_sub_f32 %3, |%3|, %9\n v_sub_f32 %4, |%4|, %10\n"
+                "v_max_f32 %2, 0, %2\n v_max_f32 %3, 0, %3\n v_max_f32 %4, 0, %4\n"
+                "v_mul_f32 %1, %2, %2\n v_fmac_f32 %1, %3, %3\n v_fmac_f32 %1, %4, %4\n"
+                "v_cmp_le_f32 vcc, %0, %5\n v_cmp_le_f32 vcc, %1, %5\n"
+                : "=&v"(k0), "=&v"(k1), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+                : "v"(a0), "v"(a1), "v"(a2), "s"(s0), "s"(s1), "s"(s2) : "vcc");
+            a3 += k0 + k1;
         } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
             REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
         }
@@ -105,6 +120,7 @@ int main() {
     run<7>("32 v_pk_fma_f32", 32, 0);
     run<9>("32 v_pk_add_f32 sgpr src", 32, 0);
     run<8>("32 v_max3_f32", 32, 0);
+    run<10>("walk box test (26 VALU)", 26, 0);
     run<2>("32 VALU + 32 SALU", 32, 32);
     run<3>("32 VALU + 16 SALU", 32, 16);
     return 0;
