@@ -51,6 +51,8 @@ def parse():
                          "min(8, N + 2) on N GPUs, where a rank's tile share no longer fills its GPU)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="diagnostic (1 GPU): render only rank 0's tile share of an N-rank frame, no gather")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the N-rank path)")
+    ap.add_argument("--device", type=int, default=-1, help="GPU index for every rank (rehearsal: N ranks on one GPU); default LOCAL_RANK")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
     ap.add_argument("--knn-points", type=int, default=10_000_000)
@@ -190,10 +192,18 @@ def profiled_traffic():
     return best[1], "bytes per launch, FETCH_SIZE + WRITE_SIZE from " + os.path.relpath(best[0], os.path.dirname(os.path.abspath(__file__)))
 
 
+def trace(msg):
+    """Stage markers for rehearsing the N-rank path (SDF_BENCH_TRACE=1)."""
+    if os.environ.get("SDF_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.device >= 0:
+        local_rank = a.device
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
@@ -204,7 +214,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -280,7 +293,13 @@ def main():
             sl = slots[k % depth]
             with torch.cuda.stream(sl.stream):
                 gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, *sl.mine_ptrs, sl.stream.cuda_stream)
-                dist.all_gather_into_tensor(sl.gathered, sl.mine)
+                if a.backend == "nccl":
+                    dist.all_gather_into_tensor(sl.gathered, sl.mine)
+                else:   # rehearsal on a CPU backend: stage through host memory (synchronous)
+                    sl.stream.synchronize()
+                    host = torch.empty(world * nbytes, dtype=torch.uint8)
+                    dist.all_gather_into_tensor(host, sl.mine.cpu())
+                    sl.gathered.copy_(host)
                 if rank == 0:
                     for (rf, rs, rc), ptrs in sl.part_ptrs:
                         gpu.untile_dev(w, h, rf, rs, rc, *ptrs, *sl.out_ptrs, sl.stream.cuda_stream)
@@ -290,9 +309,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace("setup done")
     for k in range(a.warmup):
         step(k)
+        trace(f"warmup step {k} enqueued")
     barrier()
+    trace("warmup done")
     # Duration of the dominant kernel when it has the GPU to itself (roofline): HIP events
     # around single launches on the launch stream, outside the timed region.
     kms = []
@@ -310,6 +332,7 @@ def main():
         step(k)
     barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed loop done")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
