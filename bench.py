@@ -309,6 +309,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up: every slot renders twice, so that each stream has its buffers touched and its tile
+    # schedule (recorded by the first frame on that stream) before the W warm-up steps
+    for k in range(2 * depth):
+        step(k)
+    barrier()
     trace("setup done")
     for k in range(a.warmup):
         step(k)
