@@ -42,6 +42,7 @@ struct sdfgpu_ctx {
         // longest-first tile order from the costs the previous frame on this stream recorded
         DevBuf order;               // [cost | iota | sorted keys | order] x tiles, then the sort's temp storage
         uint32_t order_tiles = 0;   // tile count the buffers are laid out for
+        size_t order_temp = 0;      // bytes of sort temp storage behind the four arrays
         uint64_t order_sig = 0;     // frame geometry the recorded costs belong to
         bool order_valid = false;
     };
@@ -206,10 +207,10 @@ int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint3
     size_t temp_bytes = 0;
     const bool single_pass = pb.size() == 2;
     if (c->tile_order && single_pass && !c->tree.gen && tile_count >= 1024 && (ms = stream_scratch(c, stream))) {
-        temp_bytes = tile_sort_temp_bytes(tile_count);
         const size_t arr = ((size_t)tile_count * sizeof(uint32_t) + 255) & ~(size_t)255;
         if (ms->order_tiles != tile_count || !ms->order.p) {
-            if ((rc = reserve(c, ms->order, 4 * arr + temp_bytes + 256))) return rc;
+            ms->order_temp = tile_sort_temp_bytes(tile_count);
+            if ((rc = reserve(c, ms->order, 4 * arr + ms->order_temp + 256))) return rc;
             ms->order_tiles = tile_count;
             ms->order_valid = false;
             HIP_TRY(c, launch_iota((uint32_t*)((char*)ms->order.p + arr), tile_count, stream));
@@ -220,6 +221,7 @@ int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint3
         keys = (uint32_t*)(base + 2 * arr);
         order = (uint32_t*)(base + 3 * arr);
         temp = base + 4 * arr;
+        temp_bytes = ms->order_temp;
         const uint64_t sig = ((uint64_t)w << 48) ^ ((uint64_t)h << 32) ^ ((uint64_t)tile_first << 16) ^ ((uint64_t)tile_stride << 8) ^
                              (uint64_t)tile_count ^ ((uint64_t)mp->max_steps << 40);
         if (ms->order_sig != sig) ms->order_valid = false;
