@@ -157,6 +157,19 @@ int sdfgpu_nearest(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n,
 int sdfgpu_nearest_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
                        float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
 
+/* Allocation-free variant of sdfgpu_nearest_dev.  NO COUNTERPART IN THE REFERENCE (the crate is a
+ * CPU library): it exists for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and bit-identical
+ * results as sdfgpu_nearest_dev; the Morton-reordering scratch (keys, permutation, radix-sort
+ * storage) lives in a file-scope __device__ array of the library (8 MiB per GPU, held until the
+ * process ends) whose device address is looked up once per device in sdfgpu_create.  The call
+ * performs no hipMalloc / hipFree.  At most SDFGPU_STATIC_MAX_POINTS points per call
+ * (SDFGPU_ERR_TOO_LARGE beyond).  Every call on a GPU -- from any context of the process -- shares
+ * that GPU's one array: calls that overlap in time on one GPU race; serialise them on a stream. */
+#define SDFGPU_STATIC_MAX_POINTS 262144u
+int sdfgpu_nearest_dev_static(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
+                              float* d_out_dist, uint32_t* d_out_prim, void* hip_stream);
+
 /* Tuning knobs.  None of them can change a result, only the time it takes.
  * No reference counterpart. */
 typedef enum sdfgpu_option {

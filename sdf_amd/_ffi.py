@@ -55,6 +55,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_HIP, ERR_NO_TREE, ERR_LAYOUT, ERR_BAD_TREE = -1, -2, -3, -4, -5
 ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE = -6, -7, -8, -9, -10
 MAX_K = 16
+STATIC_MAX_POINTS = 262144
 OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER = 0, 1, 2, 3
 
 
@@ -137,6 +138,7 @@ GPU_SYMBOLS = {
     "sdfgpu_tree_info_get": (_i, [_vp, C.POINTER(TreeInfo)]),
     "sdfgpu_nearest": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sdfgpu_nearest_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "sdfgpu_nearest_dev_static": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "sdfgpu_set_option": (_i, [_vp, _i, C.c_double]),
     "sdfgpu_knn": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "sdfgpu_knn_dev": (_i, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),

@@ -53,6 +53,9 @@ struct sdfgpu_ctx {
     bool reorder = true;
     float skip_ext_opt = 0.f;    // SDFGPU_OPT_SKIP_EXTENSION as set (< 0: half the mean primitive size)
     float mean_extent = 0.f;
+    // sdfgpu_nearest_dev_static: address of sort.hip's file-scope scratch array on this device
+    void* static_scratch = nullptr;
+    hipError_t static_scratch_err = hipSuccess;
 };
 
 namespace {
@@ -109,7 +112,7 @@ int check_march(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
 // Morton permutation of a device point batch (nullptr when reordering is off
 // or not worth it).  Scratch is grow-only, so steady-state calls allocate nothing.
 constexpr size_t REORDER_MIN_POINTS = 2048;
-int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const uint32_t** order) {
+int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const uint32_t** order, bool use_static = false) {
     *order = nullptr;
     if (!c->reorder || n < REORDER_MIN_POINTS || c->tree.gen) return SDFGPU_OK;
     float lo[3], hi[3];
@@ -120,14 +123,34 @@ int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const
         lo[a] = cen - half;
         hi[a] = cen + half;
     }
-    int rc;
     const size_t tmp = sort_temp_bytes((uint32_t)n);
-    if ((rc = reserve(c, c->keys_a, n * 4)) || (rc = reserve(c, c->keys_b, n * 4)) || (rc = reserve(c, c->idx_a, n * 4)) ||
-        (rc = reserve(c, c->idx_b, n * 4)) || (rc = reserve(c, c->sort_tmp, tmp)))
-        return rc;
-    HIP_TRY(c, launch_morton_order(d_pts, (uint32_t)n, lo, hi, (uint32_t*)c->keys_a.p, (uint32_t*)c->keys_b.p,
-                                   (uint32_t*)c->idx_a.p, (uint32_t*)c->idx_b.p, c->sort_tmp.p, tmp, s));
-    *order = (const uint32_t*)c->idx_b.p;
+    uint32_t *keys_a, *keys_b, *idx_a, *idx_b;
+    void* temp;
+    if (use_static) {
+        // the file-scope array of sort.hip, through the address looked up at sdfgpu_create: nothing is allocated
+        constexpr size_t arr = (size_t)SDFGPU_STATIC_MAX_POINTS * sizeof(uint32_t);
+        static_assert(4 * arr < STATIC_SCRATCH_BYTES, "static scratch holds the four arrays and the sort's storage");
+        if (4 * arr + tmp > STATIC_SCRATCH_BYTES)
+            return set_err(c, SDFGPU_ERR_TOO_LARGE, "radix sort storage does not fit the static scratch");
+        char* base = (char*)c->static_scratch;
+        keys_a = (uint32_t*)base;
+        keys_b = (uint32_t*)(base + arr);
+        idx_a = (uint32_t*)(base + 2 * arr);
+        idx_b = (uint32_t*)(base + 3 * arr);
+        temp = base + 4 * arr;
+    } else {
+        int rc;
+        if ((rc = reserve(c, c->keys_a, n * 4)) || (rc = reserve(c, c->keys_b, n * 4)) || (rc = reserve(c, c->idx_a, n * 4)) ||
+            (rc = reserve(c, c->idx_b, n * 4)) || (rc = reserve(c, c->sort_tmp, tmp)))
+            return rc;
+        keys_a = (uint32_t*)c->keys_a.p;
+        keys_b = (uint32_t*)c->keys_b.p;
+        idx_a = (uint32_t*)c->idx_a.p;
+        idx_b = (uint32_t*)c->idx_b.p;
+        temp = c->sort_tmp.p;
+    }
+    HIP_TRY(c, launch_morton_order(d_pts, (uint32_t)n, lo, hi, keys_a, keys_b, idx_a, idx_b, temp, tmp, s));
+    *order = idx_b;
     return SDFGPU_OK;
 }
 
@@ -282,6 +305,9 @@ int sdfgpu_create(int device_id, sdfgpu_ctx** out) {
         delete c;
         return SDFGPU_ERR_HIP;
     }
+    // device address of the allocation-free entry point's scratch (one copy per GPU), once, here,
+    // with this device current; a failure is kept and reported by sdfgpu_nearest_dev_static
+    c->static_scratch_err = static_scratch_address(device_id, &c->static_scratch);
     *out = c;
     return SDFGPU_OK;
 }
@@ -367,6 +393,26 @@ int sdfgpu_nearest_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, float* d_dis
     if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
     const uint32_t* order = nullptr;
     if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order))) return rc;
+    HIP_TRY(c, launch_nearest(c->tree, d_pts, order, (uint32_t)n, d_dist, d_prim, nullptr, (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
+// The allocation-free variant of sdfgpu_nearest_dev: same kernels, same results; the reordering
+// scratch is sort.hip's file-scope __device__ array instead of hipMalloc'ed context buffers.
+// Nothing on this path calls hipMalloc / hipFree (launch_morton_order hands hipcub its storage).
+int sdfgpu_nearest_dev_static(sdfgpu_ctx* c, const float* d_pts, size_t n, float* d_dist, uint32_t* d_prim, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (n == 0) return SDFGPU_OK;
+    if (!d_pts || !d_dist) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null device pointer");
+    if (n > SDFGPU_STATIC_MAX_POINTS)
+        return set_err(c, SDFGPU_ERR_TOO_LARGE,
+                       "sdfgpu_nearest_dev_static takes at most SDFGPU_STATIC_MAX_POINTS (262144) points per call");
+    if (c->static_scratch_err != hipSuccess || !c->static_scratch)
+        return hip_fail(c, c->static_scratch_err != hipSuccess ? c->static_scratch_err : hipErrorInvalidSymbol,
+                        "hipGetSymbolAddress(scratch) at sdfgpu_create");
+    const uint32_t* order = nullptr;
+    if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order, true))) return rc;
     HIP_TRY(c, launch_nearest(c->tree, d_pts, order, (uint32_t)n, d_dist, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
 }

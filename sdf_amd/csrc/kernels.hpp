@@ -37,6 +37,13 @@ hipError_t launch_morton_order(const float* pts_xyzw, uint32_t n, const float lo
                                uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* idx_out, void* temp,
                                size_t temp_bytes, hipStream_t s);
 
+// Scratch of the allocation-free nearest query (sort.hip): a file-scope __device__ array of
+// STATIC_SCRATCH_BYTES, laid out as four arrays of SDFGPU_STATIC_MAX_POINTS 32-bit words (Morton
+// keys in / out, permutation in / out) followed by the radix sort's temporary storage.
+// static_scratch_address returns the array's address on `device` (which must be current).
+constexpr size_t STATIC_SCRATCH_BYTES = 8u << 20;
+hipError_t static_scratch_address(int device, void** ptr);
+
 // Scratch of the multi-pass march (ray compaction): two state buffers of
 // tile_count*64 16-byte records, per-wave counts and offsets (tile_count+1), two headers.
 struct RenderScratch {

@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <cstdlib>
+#include <mutex>
 
 #include "kernels.hpp"
 
@@ -65,6 +66,33 @@ hipError_t launch_morton_order(const float* pts, uint32_t n, const float lo[3], 
     if (bits > 30) bits = 30;
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 30 - bits, 30,
                                               s);
+}
+
+// ---- scratch of the allocation-free entry point (sdfgpu_nearest_dev_static) --
+// The reordering above needs device memory beyond the caller's inputs and outputs: two key
+// arrays, two index arrays and the radix sort's temporary storage.  sdfgpu_nearest_dev keeps
+// them in grow-only hipMalloc'ed buffers of the context; the allocation-free variant keeps them
+// here, in the code object's own memory, so that it never has to allocate.  Each GPU the library
+// runs on holds its own copy of this array at its own address until the process ends; the
+// array's name is only a host-side stand-in for it, so host code asks the runtime for the
+// device address once per device and passes THAT to kernels and to hipcub.
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+hipError_t static_scratch_address(int device, void** ptr) {
+    // looked up with `device` current (the caller, sdfgpu_create, has just set it)
+    static std::mutex mu;
+    static void* known[64] = {nullptr};
+    *ptr = nullptr;
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(mu);
+    if (!known[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        known[device] = p;
+    }
+    *ptr = known[device];
+    return hipSuccess;
 }
 
 // ---- tile scheduling (render) ------------------------------------------------

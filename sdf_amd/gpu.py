@@ -99,6 +99,10 @@ class SdfGpu:
     def nearest_dev(self, d_pts, n, d_dist, d_prim, stream=0):
         self._check(self._lib.sdfgpu_nearest_dev(self._h, d_pts, n, d_dist, d_prim, stream))
 
+    def nearest_dev_static(self, d_pts, n, d_dist, d_prim, stream=0):
+        """Allocation-free variant (scratch in the library's static __device__ array)."""
+        self._check(self._lib.sdfgpu_nearest_dev_static(self._h, d_pts, n, d_dist, d_prim, stream))
+
     def nearest_stats_dev(self, d_pts, n):
         st = _ffi.Stats()
         self._check(self._lib.sdfgpu_nearest_stats_dev(self._h, d_pts, n, C.byref(st)))
