@@ -49,6 +49,11 @@ bool is_identity(const float* m) {
 
 bool bottom_row_exact(const float* m) { return m[3] == 0.f && m[7] == 0.f && m[11] == 0.f && m[15] == 1.f; }
 
+// |M^T M - I| <= RIGID_TOL elementwise.  Pruned bounds compare world-space box distances with leaf
+// values, which is sound only while a leaf value is at least (1 - ~RIGID_TOL/2) x the world distance:
+// the kernels' relative slack (1.0006 on squared distances, 0.9996 on kept bounds) covers that with
+// room to spare; the march's budget decrement uses the measured constant (lipschitz3) itself.
+constexpr double RIGID_TOL = 2e-5;
 bool rigid3(const float* m, double tol) {
     // columns c of the 3x3: m[4c + r]
     for (int a = 0; a < 3; ++a)
@@ -58,6 +63,22 @@ bool rigid3(const float* m, double tol) {
             if (std::fabs(s - (a == b ? 1.0 : 0.0)) > tol) return false;
         }
     return true;
+}
+
+// Upper bound on the largest singular value of the 3x3 linear part (sqrt of the infinity norm of
+// M^T M): a leaf value f(p) = PRIM(M p + t) changes by at most this much per unit the point moves.
+double lipschitz3(const float* m) {
+    double worst = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        double row = 0.0;
+        for (int b = 0; b < 3; ++b) {
+            double s = 0;
+            for (int r = 0; r < 3; ++r) s += (double)m[4 * a + r] * (double)m[4 * b + r];
+            row += std::fabs(s);
+        }
+        worst = std::max(worst, row);
+    }
+    return std::sqrt(worst);
 }
 
 float round_up(double x) {
@@ -323,6 +344,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     c.dead.assign(n, 0);
     uint32_t dead_end = 0;
     float margin_T = 0.f;
+    double lip = 1.0;   // largest leaf Lipschitz constant (1 for rigid leaves)
     for (uint32_t i = 0; i < n; ++i) {
         if (dt[i].level == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u has level 0", i);
         if (dt[i].level >= 255)
@@ -354,7 +376,8 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported primitive op code: %u (node %u)", b.op_code, i);
             }
             if (!dead && !bottom_row_exact(ti)) exact_rows = false;
-            if (!dead && !rigid3(ti, 1e-4)) rigid = false;
+            if (!dead && !rigid3(ti, RIGID_TOL)) rigid = false;
+            if (!dead) lip = std::max(lip, lipschitz3(ti));
             c.prim_id[i] = n_prims++;
         } else {
             if (b.op_code != SDF_OP_UNION && b.op_code != SDF_OP_CAA_CLONE)
@@ -454,8 +477,9 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
 
     uint32_t mode = bounds;
     if (mode == SDFGPU_BOUNDS_AUTO) mode = rigid ? SDFGPU_BOUNDS_BVH : SDFGPU_BOUNDS_NONE;
-    if ((mode == SDFGPU_BOUNDS_AABB || mode == SDFGPU_BOUNDS_BVH) && !rigid)
-        return fail(err, SDFGPU_ERR_BAD_TREE, "AABB bounds need rigid leaf transforms (trans_inverse is not orthonormal)");
+    if ((mode == SDFGPU_BOUNDS_AABB || mode == SDFGPU_BOUNDS_BVH || mode == SDFGPU_BOUNDS_OBB) && !rigid)
+        return fail(err, SDFGPU_ERR_BAD_TREE,
+                    "pruned bounds (AABB, BVH, OBB) need rigid leaf transforms (trans_inverse is not orthonormal); use AUTO or NONE");
     if (mode == SDFGPU_BOUNDS_OBB) {
         for (uint32_t i = 0; i < n; ++i) {
             const SdfBoundingBoxBlock& bb = dt[i].bounding_box;
@@ -517,6 +541,8 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     }
     out->stack_depth = std::max(1u, depth);
     out->margin_T = margin_T;
+    // budget decrement per unit of march distance: the Lipschitz constant, plus the rounding of the product
+    out->lipschitz = round_up(lip * 1.000004);
 
     sdfgpu_tree_info& info = out->info;
     info.n_prims = n_prims;

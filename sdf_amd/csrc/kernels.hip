@@ -116,12 +116,14 @@ struct TreeView {
     uint32_t n_leaf;
     float margin_T;
     float skip_ext;     // widening of the search radius that pays for skipped walks (render)
+    float lip;          // max change of any leaf value per unit the point moves, rounded up (1.000004 for rigid leaves)
 };
 
 // Absolute slack covering the rounding of a leaf value at point p (DESIGN.md "pruning").
 template <int MODE>
 __device__ __forceinline__ float prune_margin(const TreeView& T, float px, float py, float pz) {
-    const float mg_k = (MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f;
+    // T.lip scales it for non-rigid leaves (NONE mode only): the rounding of M p grows with |M|
+    const float mg_k = ((MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f) * T.lip;
     return mg_k * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + T.margin_T);
 }
 
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
                 alive = false;
             } else {
                 t = t + best;
-                budget = (budget - __builtin_fabsf(best) * 1.000004f) - mg;
+                budget = (budget - __builtin_fabsf(best) * T.lip) - mg;
                 if (t > mp.t_max) alive = false;
             }
         }
@@ -1104,6 +1106,7 @@ static TreeView make_view(const DeviceTree& d) {
     v.margin_T = d.margin_T;
     v.n_leaf = d.n_leaf;
     v.skip_ext = d.skip_ext;
+    v.lip = d.lipschitz;
     return v;
 }
 

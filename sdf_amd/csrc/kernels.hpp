@@ -21,6 +21,7 @@ struct DeviceTree {
     uint32_t bounds = SDFGPU_BOUNDS_AABB;
     float margin_T = 0.f;
     float skip_ext = 0.f;
+    float lipschitz = 1.000004f;
 };
 
 // st != nullptr selects the counting instantiation of the same kernel.

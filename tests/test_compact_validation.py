@@ -128,8 +128,9 @@ def test_non_rigid_leaf_falls_back_to_no_pruning():
     buf = mutate(good(), scale_leaf)
     rc, info, msg = S.compact_host(buf)
     assert rc == 0 and info.bounds == S.BOUNDS_NONE and info.rigid_leaves == 0
-    rc, _, msg = S.compact_host(buf, bounds=S.BOUNDS_AABB)
-    assert rc == _ffi.ERR_BAD_TREE and "rigid" in msg
+    for mode in (S.BOUNDS_AABB, S.BOUNDS_BVH, S.BOUNDS_OBB):   # every pruned mode compares world boxes with leaf values
+        rc, _, msg = S.compact_host(buf, bounds=mode)
+        assert rc == _ffi.ERR_BAD_TREE and "rigid" in msg
 
 
 def test_obb_mode_requires_affine_boxes():

@@ -246,3 +246,46 @@ def test_packed_planes_assembly_as_in_bench(gpu, world):
     got = {"hit": o_hit.cpu().numpy(), "depth": o_depth.cpu().numpy(),
            "normal": o_normal.cpu().numpy().reshape(-1, 3), "prim": o_prim.cpu().numpy().view(np.uint32)}
     _compare(got, full)
+
+
+def _scale_leaf(buf, i, s):
+    """Scale the whole world->primitive map of down-block i by s (a non-rigid leaf: its value is
+    s x the distance a rigid copy would report, minus the radius)."""
+    m = buf.downtree_buffer["bounding_box"]["trans_inverse"][i]
+    m[[0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14]] *= np.float32(s)
+
+
+@pytest.mark.parametrize("bounds", [S.BOUNDS_AUTO, S.BOUNDS_NONE])
+def test_render_non_rigid_leaves_match_exhaustive(gpu, bounds):
+    # ADVICE r1: the march's walk skipping assumed a leaf value moves at most delta when the point
+    # moves delta; a scaled leaf moves faster.  The budget now decays by the leaves' measured
+    # Lipschitz constant, so NONE mode (the only one that accepts such leaves) matches the oracle.
+    n, w, h = 120, 96, 64
+    buf = S.random_scene_buffer(n, 0x5DF00777)
+    prim_rows = np.flatnonzero(buf.downtree_buffer["is_primitive"])
+    rng = np.random.default_rng(3)
+    for i in prim_rows[rng.random(len(prim_rows)) < 0.5]:
+        _scale_leaf(buf, int(i), rng.choice([0.5, 2.0, 3.0]))
+    cam, mp = scene_camera(n, w, h)
+    info = gpu.upload_tree(buf, bounds=bounds)
+    assert info.bounds == S.BOUNDS_NONE and info.rigid_leaves == 0
+    ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
+    assert ref["hit"].sum() > 0
+    _compare(gpu.render(cam, w, h, mp), ref)
+    with pytest.raises(S.SdfGpuError):
+        gpu.upload_tree(buf, bounds=S.BOUNDS_OBB)
+
+
+def test_render_scaled_leaf_counter_example(gpu):
+    # the advisor's hand-worked case: ray from the origin along +z, rigid sphere A (r = 1) at
+    # (0, 60, 100), sphere B (r = 1) at (0, -3, 150) whose trans_inverse is scaled by 2
+    a = S.SdfBuilder.primitive(S.SdfSphere(1.0)).transform(S.Transform.from_xyz(0, 60, 100))
+    b = S.SdfBuilder.primitive(S.SdfSphere(1.0)).transform(S.Transform.from_xyz(0, -3, 150))
+    buf = a.operation(S.SdfUnion(0.0)).with_(b).finalize().expanded().make_buffer()
+    rows = np.flatnonzero(buf.downtree_buffer["is_primitive"])
+    _scale_leaf(buf, int(rows[1]), 2.0)
+    w = h = 16
+    cam = S.camera_look_at((0, 0, 0), (0, 0, 1), (0, 1, 0), 0.02, w, h)
+    mp = S.march_params(max_steps=64, eps_hit=1e-3, t_min=0.0, t_max=400.0, normal_h=1e-3)
+    gpu.upload_tree(buf)
+    _compare(gpu.render(cam, w, h, mp), O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE))

@@ -1,0 +1,348 @@
+// wave_sim.cpp -- design-exploration tool (not product code, not test infrastructure): a CPU model
+// of render_pass_kernel's wave-uniform march over the SAME resident hierarchy (compact_tree), used
+// to count wave-level node visits under different lane-scheduling strategies before building them.
+//   build: see tools/sim/Makefile      run: ./wave_sim [strategy] [threshold] [w h] [n_prims seed]
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfgpu.h"
+#include "../../include/sdfhost.h"
+#include "../../sdf_amd/csrc/gpu_tree.hpp"
+
+using namespace sdfgpu;
+
+static CompactTree T;
+static float g_lip;
+
+static inline float leaf_eval(const GpuLeaf& L, float px, float py, float pz) {
+    const float* m = L.m;
+    float lx = ((m[0] * px + m[1] * py) + m[2] * pz) + m[3];
+    float ly = ((m[4] * px + m[5] * py) + m[6] * pz) + m[7];
+    float lz = ((m[8] * px + m[9] * py) + m[10] * pz) + m[11];
+    if (L.kind == SDF_PRIM_SPHERE) return std::sqrt((lx * lx + ly * ly) + lz * lz) - L.param[0];
+    float qx = std::fabs(lx) - L.param[0], qy = std::fabs(ly) - L.param[1], qz = std::fabs(lz) - L.param[2];
+    float mx = qx > 0 ? qx : 0, my = qy > 0 ? qy : 0, mz = qz > 0 ? qz : 0;
+    float l = std::sqrt((mx * mx + my * my) + mz * mz);
+    return l + std::fmin(std::fmax(qx, std::fmax(qy, qz)), 0.0f);
+}
+static inline float aabb_d2(const float* c, const float* h, float px, float py, float pz) {
+    float dx = std::fmax(std::fabs(px - c[0]) - h[0], 0.f), dy = std::fmax(std::fabs(py - c[1]) - h[1], 0.f),
+          dz = std::fmax(std::fabs(pz - c[2]) - h[2], 0.f);
+    return std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+}
+static inline bool is_better(float d, uint32_t id, float best, uint32_t bid) {
+    return (d < best) | ((d == best) & ((id > bid) | (bid == SDF_NO_PRIM)));
+}
+
+struct Lane {
+    bool alive = false, hit = false;
+    float t = 0, budget = 0, dx = 0, dy = 0, dz = 0;
+    uint32_t last = SDF_NO_PRIM, steps = 0;
+    int pix = -1;
+    // per-step scratch
+    float px, py, pz, mg, best, second, lbk, thr;
+    uint32_t bid;
+    bool drive, certified, paused = false;
+};
+
+struct Stats {
+    uint64_t wave_steps = 0, wave_walks = 0, wave_inner = 0, wave_leaf = 0, lane_steps = 0, lane_walks = 0, lane_needed = 0,
+             lane_inner = 0;
+    uint64_t by_alive_steps[65] = {0}, by_alive_inner[65] = {0}, by_drive_walks[65] = {0}, by_drive_inner[65] = {0};
+    void add(const Stats& o) {
+        wave_steps += o.wave_steps; wave_walks += o.wave_walks; wave_inner += o.wave_inner; wave_leaf += o.wave_leaf;
+        lane_steps += o.lane_steps; lane_walks += o.lane_walks; lane_needed += o.lane_needed; lane_inner += o.lane_inner;
+        for (int i = 0; i < 65; ++i) {
+            by_alive_steps[i] += o.by_alive_steps[i]; by_alive_inner[i] += o.by_alive_inner[i];
+            by_drive_walks[i] += o.by_drive_walks[i]; by_drive_inner[i] += o.by_drive_inner[i];
+        }
+    }
+    double valu() const { return 30.0 * wave_inner + 50.0 * wave_leaf + 120.0 * wave_steps; }
+};
+
+static sdfgpu_camera cam;
+static sdfgpu_march_params mp;
+static float ox, oy, oz;
+static uint32_t W, H;
+
+static void look_at(const float eye[3], const float target[3], const float up[3], float fov_y, uint32_t width, uint32_t height,
+                    sdfgpu_camera* out) {   // same arithmetic as sdfgpu_camera_look_at (api.cpp needs the HIP runtime)
+    double f[3], r[3], u[3], fl = 0, rl = 0;
+    for (int i = 0; i < 3; ++i) { f[i] = (double)target[i] - (double)eye[i]; fl += f[i] * f[i]; }
+    fl = std::sqrt(fl);
+    for (int i = 0; i < 3; ++i) f[i] /= fl;
+    r[0] = f[1] * up[2] - f[2] * up[1]; r[1] = f[2] * up[0] - f[0] * up[2]; r[2] = f[0] * up[1] - f[1] * up[0];
+    for (int i = 0; i < 3; ++i) rl += r[i] * r[i];
+    rl = std::sqrt(rl);
+    for (int i = 0; i < 3; ++i) r[i] /= rl;
+    u[0] = r[1] * f[2] - r[2] * f[1]; u[1] = r[2] * f[0] - r[0] * f[2]; u[2] = r[0] * f[1] - r[1] * f[0];
+    const double half_h = std::tan(0.5 * (double)fov_y), half_w = half_h * (double)width / (double)height;
+    const double sx = 2.0 * half_w / (double)width, sy = 2.0 * half_h / (double)height;
+    for (int i = 0; i < 3; ++i) {
+        out->eye[i] = eye[i];
+        out->du[i] = (float)(r[i] * sx);
+        out->dv[i] = (float)(-u[i] * sy);
+        out->origin[i] = (float)((double)eye[i] + f[i] - r[i] * (half_w - 0.5 * sx) + u[i] * (half_h - 0.5 * sy));
+    }
+}
+
+static void init_ray(Lane& l, int x, int y) {
+    l = Lane();
+    l.pix = y * (int)W + x;
+    l.alive = x < (int)W && y < (int)H;
+    float fx = (float)x, fy = (float)y;
+    float dx = ((cam.origin[0] + cam.du[0] * fx) + cam.dv[0] * fy) - ox;
+    float dy = ((cam.origin[1] + cam.du[1] * fx) + cam.dv[1] * fy) - oy;
+    float dz = ((cam.origin[2] + cam.du[2] * fx) + cam.dv[2] * fy) - oz;
+    float dl = std::sqrt((dx * dx + dy * dy) + dz * dz);
+    l.dx = dx / dl; l.dy = dy / dl; l.dz = dz / dl;
+    l.t = mp.t_min;
+}
+
+// one wave-uniform walk for the lanes with drive set; returns wave-level inner visits
+static void walk(Lane* L, Stats& st) {
+    uint32_t cur = T.root_ref;
+    if (cur == REF_NONE) return;
+    struct E { uint32_t ref; float k[64]; };
+    static thread_local std::vector<E> stk(128);
+    uint32_t sp = 0;
+    int ndrive = 0;
+    for (int i = 0; i < 64; ++i) {
+        ndrive += L[i].drive;
+        float bp = std::fmax(L[i].best + L[i].mg, 0.f);
+        L[i].thr = bp * bp * 1.0006f;
+    }
+    uint64_t inner0 = st.wave_inner;
+    for (;;) {
+        while (!(cur & REF_LEAF)) {
+            const GpuInner& N = T.inner[cur];
+            float k0[64], k1[64];
+            bool any0 = false, any1 = false;
+            int n0 = 0, nt = 0;
+            st.wave_inner++;
+            for (int i = 0; i < 64; ++i) {
+                k0[i] = aabb_d2(N.c0, N.h0, L[i].px, L[i].py, L[i].pz);
+                k1[i] = aabb_d2(N.c1, N.h1, L[i].px, L[i].py, L[i].pz);
+                if (!L[i].drive) continue;
+                st.lane_inner++;
+                bool m0 = k0[i] <= L[i].thr, m1 = k1[i] <= L[i].thr;
+                any0 |= m0; any1 |= m1;
+                if (m0 | m1) { nt++; st.lane_needed++; }
+                if (m0 && (k0[i] <= k1[i] || !m1)) n0++;
+            }
+            if (any0 && any1) {
+                bool first0 = 2 * n0 >= nt;
+                E& e = stk[sp++];
+                e.ref = first0 ? N.ref1 : N.ref0;
+                for (int i = 0; i < 64; ++i) e.k[i] = first0 ? k1[i] : k0[i];
+                cur = first0 ? N.ref0 : N.ref1;
+            } else if (any0) {
+                for (int i = 0; i < 64; ++i) L[i].lbk = std::fmin(L[i].lbk, k1[i]);
+                cur = N.ref0;
+            } else if (any1) {
+                for (int i = 0; i < 64; ++i) L[i].lbk = std::fmin(L[i].lbk, k0[i]);
+                cur = N.ref1;
+            } else {
+                for (int i = 0; i < 64; ++i) L[i].lbk = std::fmin(L[i].lbk, std::fmin(k0[i], k1[i]));
+                cur = REF_NONE;
+                break;
+            }
+        }
+        if (cur != REF_NONE) {
+            uint32_t id = cur & REF_INDEX;
+            st.wave_leaf++;
+            for (int i = 0; i < 64; ++i) {
+                float d = leaf_eval(T.leaves[id], L[i].px, L[i].py, L[i].pz);
+                bool rival = id != L[i].bid;
+                bool b = rival && is_better(d, id, L[i].best, L[i].bid);
+                float loser = b ? L[i].best : d;
+                if (rival && loser < L[i].second) L[i].second = loser;
+                if (b) { L[i].best = d; L[i].bid = id; }
+                float bp = std::fmax(L[i].best + L[i].mg, 0.f);
+                L[i].thr = bp * bp * 1.0006f;
+            }
+        }
+        // pop
+        bool got = false;
+        while (sp > 0) {
+            E& e = stk[--sp];
+            bool any = false;
+            for (int i = 0; i < 64; ++i) any |= L[i].drive && e.k[i] <= L[i].thr;
+            if (any) { cur = e.ref; got = true; break; }
+            for (int i = 0; i < 64; ++i) L[i].lbk = std::fmin(L[i].lbk, e.k[i]);
+        }
+        if (!got) break;
+    }
+    st.by_drive_walks[ndrive]++;
+    st.by_drive_inner[ndrive] += st.wave_inner - inner0;
+}
+
+// One march step of a wave.  defer_thr > 0: lanes that cannot certify wait (do not advance) while fewer than
+// defer_thr of them are waiting and some certified lane can still advance.
+static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finished) {
+    int nalive = 0, nunc = 0, ncert = 0;
+    for (int i = 0; i < 64; ++i) {
+        Lane& l = L[i];
+        l.drive = false; l.certified = false;
+        l.best = INFINITY; l.bid = SDF_NO_PRIM; l.second = INFINITY; l.lbk = INFINITY;
+        if (!l.alive) continue;
+        nalive++;
+        l.px = ox + l.dx * l.t; l.py = oy + l.dy * l.t; l.pz = oz + l.dz * l.t;
+        l.mg = 3.0e-6f * g_lip * (std::fabs(l.px) + std::fabs(l.py) + std::fabs(l.pz) + T.margin_T);
+        if (l.last != SDF_NO_PRIM) {
+            l.best = leaf_eval(T.leaves[l.last], l.px, l.py, l.pz);
+            l.bid = l.last;
+            l.certified = (l.best + 2.0f * l.mg) < l.budget;
+        }
+        l.drive = !l.certified;
+        nunc += l.drive; ncert += l.certified;
+    }
+    if (nalive == 0) return;
+    st.wave_steps++;
+    st.by_alive_steps[nalive]++;
+    uint64_t inner0 = st.wave_inner;
+    bool do_walk = nunc > 0;
+    bool deferring = false;
+    if (defer_thr > 0 && nunc > 0 && nunc < defer_thr && ncert > 0) { do_walk = false; deferring = true; }
+    if (do_walk) {
+        st.wave_walks++;
+        st.lane_walks += nunc;
+        walk(L, st);
+    }
+    st.by_alive_inner[nalive] += st.wave_inner - inner0;
+    for (int i = 0; i < 64; ++i) {
+        Lane& l = L[i];
+        if (!l.alive) continue;
+        if (deferring && l.drive) continue;   // waits: same point next time
+        if (do_walk) {
+            float lb = std::fmin(std::sqrt(l.lbk) * 0.9996f, l.second) - l.mg;
+            l.budget = l.certified ? std::fmax(l.budget, lb) : lb;
+        }
+        l.steps++;
+        st.lane_steps++;
+        l.last = l.bid;
+        if (l.best < mp.eps_hit) { l.hit = true; l.alive = false; }
+        else {
+            l.t = l.t + l.best;
+            l.budget = (l.budget - std::fabs(l.best) * g_lip) - l.mg;
+            if (l.t > mp.t_max) l.alive = false;
+        }
+        if (l.alive && l.steps >= mp.max_steps) l.alive = false;
+        if (!l.alive && finished) finished->push_back(l.pix);
+    }
+}
+
+int main(int argc, char** argv) {
+    std::string strat = argc > 1 ? argv[1] : "tile";
+    int thr = argc > 2 ? atoi(argv[2]) : 32;
+    W = argc > 3 ? atoi(argv[3]) : 1920;
+    H = argc > 4 ? atoi(argv[4]) : 1080;
+    uint32_t n_prims = argc > 5 ? atoi(argv[5]) : 10000;
+    uint64_t seed = argc > 6 ? strtoull(argv[6], nullptr, 0) : 0x5DF00003ull;
+    int defer = argc > 7 ? atoi(argv[7]) : 0;
+    int tw = argc > 8 ? atoi(argv[8]) : 8, th = 64 / tw;
+
+    sdfhost_node* node = sdfhost_random_scene(n_prims, seed, 0.f, nullptr);
+    sdfhost_expanded* ex = sdfhost_expanded_new(node, nullptr);
+    sdfhost_buffer* buf = sdfhost_make_buffer(ex, nullptr);
+    std::string err;
+    int rc = compact_tree(sdfhost_buffer_downtree(buf), sdfhost_buffer_uptree(buf), sdfhost_buffer_len(buf), 0, SDFGPU_BOUNDS_AUTO, &T, &err);
+    if (rc) { fprintf(stderr, "compact: %s\n", err.c_str()); return 1; }
+    g_lip = T.lipschitz;
+    float L = sdfhost_default_extent(n_prims);
+    float eye[3] = {0, 0, -2.5f * L}, tgt[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+    look_at(eye, tgt, up, (float)(M_PI / 4), W, H, &cam);
+    mp = {128, 1e-3f, 0.f, 6.0f * L, 1e-4f, 0};
+    ox = cam.eye[0]; oy = cam.eye[1]; oz = cam.eye[2];
+
+    const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th, n_tiles = tiles_x * tiles_y;
+    Stats gst;
+    std::vector<double> wave_cost;   // per-wave VALU (critical path)
+    if (strat == "tile") {
+        wave_cost.resize(n_tiles);
+#pragma omp parallel for schedule(dynamic, 16)
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            Stats st;
+            Lane Ls[64];
+            for (int i = 0; i < 64; ++i) init_ray(Ls[i], (t % tiles_x) * tw + i % tw, (t / tiles_x) * th + i / tw);
+            double c0 = st.valu();
+            for (;;) {
+                bool any = false;
+                for (auto& l : Ls) any |= l.alive;
+                if (!any) break;
+                wave_step(Ls, st, defer, nullptr);
+            }
+            wave_cost[t] = st.valu() - c0;
+#pragma omp critical
+            gst.add(st);
+        }
+    } else if (strat == "refill") {
+        // persistent waves, each owning a contiguous strip of `strip` tiles; dead lanes are refilled from the strip's
+        // pixel stream when alive <= thr
+        const uint32_t strip = argc > 9 ? atoi(argv[9]) : 16;
+        wave_cost.resize((n_tiles + strip - 1) / strip);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += strip) {
+            Stats st;
+            Lane Ls[64];
+            uint64_t next = (uint64_t)t0 * 64, end = (uint64_t)std::min(n_tiles, t0 + strip) * 64;
+            double c0 = st.valu();
+            for (;;) {
+                int nalive = 0;
+                for (auto& l : Ls) nalive += l.alive;
+                if (nalive <= thr && next < end) {
+                    for (int i = 0; i < 64 && next < end; ++i)
+                        if (!Ls[i].alive) {
+                            uint32_t t = next >> 6, p = next & 63; next++;
+                            init_ray(Ls[i], (t % tiles_x) * tw + p % tw, (t / tiles_x) * th + p / tw);
+                        }
+                    nalive = 0;
+                    for (auto& l : Ls) nalive += l.alive;
+                }
+                if (nalive == 0) { if (next >= end) break; else continue; }
+                wave_step(Ls, st, defer, nullptr);
+            }
+            wave_cost[t0 / strip] = st.valu() - c0;
+#pragma omp critical
+            gst.add(st);
+        }
+    }
+    Stats& st = gst;
+    printf("strategy %s thr %d defer %d tile %dx%d\n", strat.c_str(), thr, defer, tw, th);
+    printf("wave_steps %lu wave_walks %lu wave_inner %lu wave_leaf %lu lane_steps %lu lane_walks %lu\n", st.wave_steps, st.wave_walks,
+           st.wave_inner, st.wave_leaf, st.lane_steps, st.lane_walks);
+    printf("inner/walk %.1f lane_inner/lane_walk %.1f needed/lane_walk %.1f  VALU est %.3fe9\n", (double)st.wave_inner / st.wave_walks,
+           (double)st.lane_inner / st.lane_walks, (double)st.lane_needed / st.lane_walks, st.valu() / 1e9);
+    std::sort(wave_cost.begin(), wave_cost.end());
+    printf("waves %zu  max wave VALU %.0f  p99 %.0f  median %.0f\n", wave_cost.size(), wave_cost.back(),
+           wave_cost[wave_cost.size() * 99 / 100], wave_cost[wave_cost.size() / 2]);
+    const int edges[] = {1, 2, 4, 8, 16, 32, 48, 63, 64};
+    int lo = 1;
+    printf("alive bucket: share of wave-steps, share of inner visits, inner per step\n");
+    uint64_t ts = 0, ti = 0;
+    for (int a = 1; a <= 64; ++a) { ts += st.by_alive_steps[a]; ti += st.by_alive_inner[a]; }
+    for (int e : edges) {
+        uint64_t s = 0, in = 0;
+        for (int a = lo; a <= e; ++a) { s += st.by_alive_steps[a]; in += st.by_alive_inner[a]; }
+        printf("  %2d..%2d: %.3f %.3f %.1f\n", lo, e, (double)s / ts, (double)in / ti, s ? (double)in / s : 0.0);
+        lo = e + 1;
+    }
+    lo = 1;
+    printf("drive bucket: share of walks, share of inner visits, inner per walk\n");
+    uint64_t tw_ = 0;
+    for (int a = 1; a <= 64; ++a) tw_ += st.by_drive_walks[a];
+    for (int e : edges) {
+        uint64_t s = 0, in = 0;
+        for (int a = lo; a <= e; ++a) { s += st.by_drive_walks[a]; in += st.by_drive_inner[a]; }
+        printf("  %2d..%2d: %.3f %.3f %.1f\n", lo, e, (double)s / tw_, (double)in / ti, s ? (double)in / s : 0.0);
+        lo = e + 1;
+    }
+    return 0;
+}
