@@ -49,6 +49,23 @@ __device__ __forceinline__ float prim_value(uint32_t kind, float p0, float p1, f
     return l + __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
 }
 
+// The same value for a per-lane `kind` (the march's seed, the normal taps), where a wavefront mixes
+// spheres and boxes: both squared lengths are formed, the lane's own goes through ONE correctly
+// rounded sqrt (its refinement is ~15 instructions, more than either formula around it), and the
+// result is finished per kind.  Every operation a lane keeps is the one prim_value performs, in the
+// same order, so the bits are the same.
+__device__ __forceinline__ float prim_value_lane(uint32_t kind, float p0, float p1, float p2, float lx, float ly,
+                                                 float lz) {
+    const float qx = __builtin_fabsf(lx) - p0, qy = __builtin_fabsf(ly) - p1, qz = __builtin_fabsf(lz) - p2;
+    const float mx = qx > 0.f ? qx : 0.f, my = qy > 0.f ? qy : 0.f, mz = qz > 0.f ? qz : 0.f;
+    const float ab = (mx * mx + my * my) + mz * mz;
+    const float as = (lx * lx + ly * ly) + lz * lz;
+    const bool sph = kind == SDF_PRIM_SPHERE;
+    const float r = __builtin_sqrtf(sph ? as : ab);
+    const float in = __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
+    return sph ? r - p0 : r + in;
+}
+
 // Per-lane evaluation of one leaf record (the march's seed, the normal taps): the whole 64-byte
 // line is requested at once, so that a box does not pay a second memory round trip for the
 // half extents its kind selects.
@@ -60,7 +77,7 @@ __device__ __forceinline__ float leaf_eval(const GpuLeaf* __restrict__ L, float 
     const float lx = ((r0.x * px + r0.y * py) + r0.z * pz) + r0.w;
     const float ly = ((r1.x * px + r1.y * py) + r1.z * pz) + r1.w;
     const float lz = ((r2.x * px + r2.y * py) + r2.z * pz) + r2.w;
-    return prim_value(__builtin_bit_cast(uint32_t, r3.w), r3.x, r3.y, r3.z, lx, ly, lz);
+    return prim_value_lane(__builtin_bit_cast(uint32_t, r3.w), r3.x, r3.y, r3.z, lx, ly, lz);
 }
 
 // (distance, index) order of the reference's union combine composed over the
@@ -364,17 +381,17 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "v_fmac_f32 %[k1], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k1], %[c], %[c]\n\t"                                                               \
     "v_cmp_le_f32 vcc, %[k0], %[thr]\n\t"                                                              \
-    "s_and_b64 %[m0], vcc, %[drive]\n\t"                                                               \
+    "s_and_b64 %[mk0], vcc, %[drive]\n\t"                                                               \
     "v_cmp_le_f32 vcc, %[k1], %[thr]\n\t"                                                              \
     "s_cbranch_scc0 .Lno0%=\n\t"                                                                       \
-    "s_and_b64 %[m1], vcc, %[drive]\n\t"                                                               \
+    "s_and_b64 %[mk1], vcc, %[drive]\n\t"                                                               \
     "s_cbranch_scc0 .Lonly0%=\n\t"                                                                     \
     /* both children needed by someone: lanes that need one vote for the nearer */                    \
     "v_cmp_le_f32 vcc, %[k0], %[k1]\n\t"                                                               \
-    "s_orn2_b64 %[t], vcc, %[m1]\n\t"                                                                  \
-    "s_and_b64 %[t], %[t], %[m0]\n\t"                                                                  \
+    "s_orn2_b64 %[t], vcc, %[mk1]\n\t"                                                                  \
+    "s_and_b64 %[t], %[t], %[mk0]\n\t"                                                                  \
     "s_bcnt1_i32_b64 %[t0], %[t]\n\t"                                                                  \
-    "s_or_b64 %[t], %[m0], %[m1]\n\t"                                                                  \
+    "s_or_b64 %[t], %[mk0], %[mk1]\n\t"                                                                  \
     "s_bcnt1_i32_b64 %[t1], %[t]\n\t"                                                                  \
     "s_lshl_b32 %[t0], %[t0], 1\n\t"                                                                   \
     "s_cmp_ge_u32 %[t0], %[t1]\n\t"          /* SCC = child 0 first */                                 \
@@ -395,7 +412,7 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_branch .Ltop%=\n"                                                                               \
     ".Lno0%=:\n\t"                                                                                     \
     LBMIN_K0                                                                                           \
-    "s_and_b64 %[m1], vcc, %[drive]\n\t"                                                               \
+    "s_and_b64 %[mk1], vcc, %[drive]\n\t"                                                               \
     "s_cbranch_scc0 .Lnone%=\n\t"                                                                      \
     "s_mov_b32 %[cur], s93\n\t"                                                                        \
     "s_branch .Ltop%=\n"                                                                               \
@@ -440,8 +457,8 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_load_dword s96, %[t], %[t0]\n\t"                                                                \
     "s_lshl_b32 %[t1], s93, 6\n\t"                                                                     \
     "s_bitcmp1_b32 s93, 31\n\t"                                                                        \
-    "s_cselect_b64 %[m0], %[lbase], %[base]\n\t"                                                       \
-    "s_load_dword s97, %[m0], %[t1]\n\t"
+    "s_cselect_b64 %[mk0], %[lbase], %[base]\n\t"                                                       \
+    "s_load_dword s97, %[mk0], %[t1]\n\t"
 #endif
 
 template <bool TRACK>
@@ -452,12 +469,15 @@ __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& r
     uint32_t t0, t1;
     float a, b, c, d, k0, k1;
 #define SDFGPU_WALK_OPERANDS                                                                                          \
-    : [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [m0] "=&s"(m0), [m1] "=&s"(m1), [t] "=&s"(t), \
+    : [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [mk0] "=&s"(m0), [mk1] "=&s"(m1), [t] "=&s"(t), \
       [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [k0] "=&v"(k0),          \
       [k1] "=&v"(k1), [rec] "=&s"(rec)                                                                                \
     : [thr] "v"(thr), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [drive] "s"(drive), [base] "s"(base), [lbase] "s"(lbase), [sa] "v"(sa)      \
     : "vcc", "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",       \
       "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+    // The block writes M0 (lane select of v_writelane).  M0 is a reserved register to this compiler: it
+    // never keeps a value live in it across other code and re-materialises it before each use of its own,
+    // so it cannot be listed as a clobber (-Winline-asm: "clobber list contains reserved registers: m0").
     if constexpr (TRACK) {
         asm volatile(SDFGPU_WALK_ASM("v_min_f32 %[lb], %[lb], %[k0]\n\t", "v_min_f32 %[lb], %[lb], %[k1]\n\t",
                                      "v_min_f32 %[lb], %[lb], %[a]\n\t", SDFGPU_WALK_PREFETCH) SDFGPU_WALK_OPERANDS);
@@ -742,9 +762,6 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     dy = dy / dl;
     dz = dz / dl;
 
-    bool hit = false;
-    uint32_t hit_prim = SDF_NO_PRIM;
-    uint32_t steps = 0;
     float px = 0.f, py = 0.f, pz = 0.f;
     // `budget`: proven lower bound, at the current point, on the distance of every
     // primitive other than `last`.  While last's own (exactly evaluated) distance
@@ -763,38 +780,38 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     const float ext = T.skip_ext;
     WaveCounters wc;
     uint32_t s = pa.step_begin;                  // this lane's step index (lanes no longer share one)
-    bool active = alive && s < pa.step_end;      // still marching in this pass
     uint32_t n_walks = 0, n_cheap = 0;
+    // Lane state as data, not control flow: 0 = marching, 1 = hit, 2 = ended without a hit (left the
+    // scene, off the image, not a ray).  The loop body is straight-line selects; the only branches are
+    // wave-uniform (walk or not).
+    uint32_t state = alive ? 0u : 2u;
     // record of `last`, kept in registers between walks: certified steps touch no memory
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
-    if (active && last != SDF_NO_PRIM) {
+    if (alive && last != SDF_NO_PRIM) {
         const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
         c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
     }
     for (;;) {
+        const bool active = (state == 0u) & (s < pa.step_end);      // still marching in this pass
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        if (active) {
-            px = ox + dx * t;
-            py = oy + dy * t;
-            pz = oz + dz * t;
-        }
+        // a lane that is not marching recomputes the point it stopped at (t is no longer advanced)
+        px = ox + dx * t;
+        py = oy + dy * t;
+        pz = oz + dz * t;
         const float mg = prune_margin<MODE>(T, px, py, pz);
-        float best = __builtin_inff();
-        uint32_t bid = SDF_NO_PRIM;
-        bool certified = false;
-        if (active && last != SDF_NO_PRIM) {
-            const float lx = ((c0.x * px + c0.y * py) + c0.z * pz) + c0.w;
-            const float ly = ((c1.x * px + c1.y * py) + c1.z * pz) + c1.w;
-            const float lz = ((c2.x * px + c2.y * py) + c2.z * pz) + c2.w;
-            best = prim_value(__builtin_bit_cast(uint32_t, c3.w), c3.x, c3.y, c3.z, lx, ly, lz);
-            bid = last;
-            certified = (best + 2.0f * mg) < budget;
-        }
+        const bool seeded = last != SDF_NO_PRIM;
+        const float lx = ((c0.x * px + c0.y * py) + c0.z * pz) + c0.w;
+        const float ly = ((c1.x * px + c1.y * py) + c1.z * pz) + c1.w;
+        const float lz = ((c2.x * px + c2.y * py) + c2.z * pz) + c2.w;
+        const float seed = prim_value_lane(__builtin_bit_cast(uint32_t, c3.w), c3.x, c3.y, c3.z, lx, ly, lz);
+        float best = seeded ? seed : __builtin_inff();
+        uint32_t bid = last;
+        const bool certified = active & seeded & ((best + 2.0f * mg) < budget);
         if constexpr (COUNT) wc.wave_steps += 1;
         bool adv;
-        const bool cheap = __builtin_amdgcn_ballot_w64(active && certified) != 0ull;
+        const bool cheap = __builtin_amdgcn_ballot_w64(certified) != 0ull;
         if (cheap) {
-            adv = active && certified;   // the others hold their position
+            adv = certified;   // the others hold their position
             n_cheap += 1;
         } else {
             // no marching lane can certify: one walk for all of them
@@ -804,39 +821,40 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
             nn_traverse<MODE, COUNT>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
             best = acc.best;
             bid = acc.bid;
-            float lb = (MODE == SDFGPU_BOUNDS_OBB) ? acc.lb_key : __builtin_sqrtf(acc.lb_key);
+            // a bound, not a result: the hardware square root (1 ulp) is inside the 0.9996
+            float lb = (MODE == SDFGPU_BOUNDS_OBB) ? acc.lb_key : __builtin_amdgcn_sqrtf(acc.lb_key);
             lb = __builtin_fminf(lb * 0.9996f, acc.second) - mg;
             // only for the lanes the walk was for: a lane that has finished this pass's steps keeps the
-            // budget it carries to the next pass (the walk saw its previous point, not its next one)
+            // budget it carries to the next pass (the walk saw the point it stopped at, not its next one)
             budget = active ? lb : budget;
             adv = active;
             n_walks += 1;
         }
-        if (adv) {
-            if constexpr (COUNT) {
-                if (last != SDF_NO_PRIM) {   // the seed evaluation of this step
-                    if (__builtin_bit_cast(uint32_t, c3.w) == SDF_PRIM_SPHERE) wc.lane_sphere += 1; else wc.lane_box += 1;
-                }
+        if constexpr (COUNT) {
+            if (adv & seeded) {   // the seed evaluation of this step
+                if (__builtin_bit_cast(uint32_t, c3.w) == SDF_PRIM_SPHERE) wc.lane_sphere += 1; else wc.lane_box += 1;
             }
-            steps += 1;
-            s += 1;
-            last = bid;
-            if (best < mp.eps_hit) {
-                hit = true;
-                hit_prim = bid;
-                alive = false;
-            } else {
-                t = t + best;
-                budget = (budget - __builtin_fabsf(best) * T.lip) - mg;
-                if (t > mp.t_max) alive = false;
-            }
-            active = alive && s < pa.step_end;
         }
-        if (!cheap && active) {   // the walk may have changed `last`: fetch its record once
-            const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
-            c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
+        const bool hit_now = adv & (best < mp.eps_hit);
+        const bool go = adv & !hit_now;
+        const float tn = t + best;
+        const float bn = (budget - __builtin_fabsf(best) * T.lip) - mg;
+        t = go ? tn : t;
+        budget = go ? bn : budget;
+        last = adv ? bid : last;
+        s += adv ? 1u : 0u;
+        state = hit_now ? 1u : ((go & (tn > mp.t_max)) ? 2u : state);
+        if (!cheap) {   // the walk may have changed `last`: fetch its record once
+            if ((state == 0u) & (s < pa.step_end)) {
+                const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
+                c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
+            }
         }
     }
+    const uint32_t steps = s - pa.step_begin;
+    const bool hit = state == 1u;
+    const uint32_t hit_prim = hit ? last : SDF_NO_PRIM;
+    alive = state == 0u;   // reached the end of this pass still marching
 
     if constexpr (FIRST) {
         if (pa.tile_cost && lane == 0) {

@@ -19,6 +19,8 @@
 using namespace sdfgpu;
 
 static CompactTree T;
+static bool g_k2 = false;
+static float g_ext = 0.f;
 static float g_lip;
 
 static inline float leaf_eval(const GpuLeaf& L, float px, float py, float pz) {
@@ -44,21 +46,21 @@ static inline bool is_better(float d, uint32_t id, float best, uint32_t bid) {
 struct Lane {
     bool alive = false, hit = false;
     float t = 0, budget = 0, dx = 0, dy = 0, dz = 0;
-    uint32_t last = SDF_NO_PRIM, steps = 0;
+    uint32_t last = SDF_NO_PRIM, last2 = SDF_NO_PRIM, sid = SDF_NO_PRIM, steps = 0;
     int pix = -1;
     // per-step scratch
-    float px, py, pz, mg, best, second, lbk, thr;
+    float px, py, pz, mg, best, second, third, lbk, thr;
     uint32_t bid;
     bool drive, certified, paused = false;
 };
 
 struct Stats {
     uint64_t wave_steps = 0, wave_walks = 0, wave_inner = 0, wave_leaf = 0, lane_steps = 0, lane_walks = 0, lane_needed = 0,
-             lane_inner = 0;
+             lane_inner = 0, chain_inner = 0;
     uint64_t by_alive_steps[65] = {0}, by_alive_inner[65] = {0}, by_drive_walks[65] = {0}, by_drive_inner[65] = {0};
     void add(const Stats& o) {
         wave_steps += o.wave_steps; wave_walks += o.wave_walks; wave_inner += o.wave_inner; wave_leaf += o.wave_leaf;
-        lane_steps += o.lane_steps; lane_walks += o.lane_walks; lane_needed += o.lane_needed; lane_inner += o.lane_inner;
+        lane_steps += o.lane_steps; lane_walks += o.lane_walks; lane_needed += o.lane_needed; lane_inner += o.lane_inner; chain_inner += o.chain_inner;
         for (int i = 0; i < 65; ++i) {
             by_alive_steps[i] += o.by_alive_steps[i]; by_alive_inner[i] += o.by_alive_inner[i];
             by_drive_walks[i] += o.by_drive_walks[i]; by_drive_inner[i] += o.by_drive_inner[i];
@@ -116,10 +118,11 @@ static void walk(Lane* L, Stats& st) {
     int ndrive = 0;
     for (int i = 0; i < 64; ++i) {
         ndrive += L[i].drive;
-        float bp = std::fmax(L[i].best + L[i].mg, 0.f);
+        float bp = std::fmax(L[i].best + L[i].mg, 0.f) + g_ext;
         L[i].thr = bp * bp * 1.0006f;
     }
     uint64_t inner0 = st.wave_inner;
+    bool chain = true;
     for (;;) {
         while (!(cur & REF_LEAF)) {
             const GpuInner& N = T.inner[cur];
@@ -137,7 +140,9 @@ static void walk(Lane* L, Stats& st) {
                 if (m0 | m1) { nt++; st.lane_needed++; }
                 if (m0 && (k0[i] <= k1[i] || !m1)) n0++;
             }
+            if (chain && !(any0 && any1)) st.chain_inner++;
             if (any0 && any1) {
+                chain = false;
                 bool first0 = 2 * n0 >= nt;
                 E& e = stk[sp++];
                 e.ref = first0 ? N.ref1 : N.ref0;
@@ -160,12 +165,26 @@ static void walk(Lane* L, Stats& st) {
             st.wave_leaf++;
             for (int i = 0; i < 64; ++i) {
                 float d = leaf_eval(T.leaves[id], L[i].px, L[i].py, L[i].pz);
+                if (g_k2) {
+                    Lane& l = L[i];
+                    if (id == l.bid || id == l.sid) continue;   // a tracked seed met again
+                    if (is_better(d, id, l.best, l.bid)) {
+                        if (l.second < l.third) l.third = l.second;
+                        l.second = l.best; l.sid = l.bid; l.best = d; l.bid = id;
+                    } else if (is_better(d, id, l.second, l.sid)) {
+                        if (l.second < l.third) l.third = l.second;
+                        l.second = d; l.sid = id;
+                    } else if (d < l.third) l.third = d;
+                    float bp = std::fmax(l.best + l.mg, 0.f);
+                    l.thr = bp * bp * 1.0006f;
+                    continue;
+                }
                 bool rival = id != L[i].bid;
                 bool b = rival && is_better(d, id, L[i].best, L[i].bid);
                 float loser = b ? L[i].best : d;
-                if (rival && loser < L[i].second) L[i].second = loser;
+                if (rival && loser < L[i].second) { L[i].second = loser; L[i].sid = b ? L[i].bid : id; }
                 if (b) { L[i].best = d; L[i].bid = id; }
-                float bp = std::fmax(L[i].best + L[i].mg, 0.f);
+                float bp = std::fmax(L[i].best + L[i].mg, 0.f) + g_ext;
                 L[i].thr = bp * bp * 1.0006f;
             }
         }
@@ -196,9 +215,15 @@ static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finis
         nalive++;
         l.px = ox + l.dx * l.t; l.py = oy + l.dy * l.t; l.pz = oz + l.dz * l.t;
         l.mg = 3.0e-6f * g_lip * (std::fabs(l.px) + std::fabs(l.py) + std::fabs(l.pz) + T.margin_T);
+        l.third = INFINITY; l.sid = SDF_NO_PRIM;
         if (l.last != SDF_NO_PRIM) {
             l.best = leaf_eval(T.leaves[l.last], l.px, l.py, l.pz);
             l.bid = l.last;
+            if (g_k2 && l.last2 != SDF_NO_PRIM) {
+                float d2 = leaf_eval(T.leaves[l.last2], l.px, l.py, l.pz);
+                if (is_better(d2, l.last2, l.best, l.bid)) { l.second = l.best; l.sid = l.bid; l.best = d2; l.bid = l.last2; }
+                else { l.second = d2; l.sid = l.last2; }
+            }
             l.certified = (l.best + 2.0f * l.mg) < l.budget;
         }
         l.drive = !l.certified;
@@ -212,6 +237,14 @@ static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finis
     bool deferring = false;
     if (defer_thr > 0 && nunc > 0 && nunc < defer_thr && ncert > 0) { do_walk = false; deferring = true; }
     if (do_walk) {
+        if (getenv("SIM_SEED2"))
+            for (int i = 0; i < 64; ++i) {
+                Lane& l = L[i];
+                if (!l.alive || l.last2 == SDF_NO_PRIM || l.last2 == l.bid) continue;
+                float d = leaf_eval(T.leaves[l.last2], l.px, l.py, l.pz);
+                if (is_better(d, l.last2, l.best, l.bid)) { l.best = d; l.bid = l.last2; }
+            }
+        if (!g_k2) for (int i = 0; i < 64; ++i) L[i].sid = SDF_NO_PRIM;
         st.wave_walks++;
         st.lane_walks += nunc;
         walk(L, st);
@@ -222,12 +255,13 @@ static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finis
         if (!l.alive) continue;
         if (deferring && l.drive) continue;   // waits: same point next time
         if (do_walk) {
-            float lb = std::fmin(std::sqrt(l.lbk) * 0.9996f, l.second) - l.mg;
+            float lb = std::fmin(std::sqrt(l.lbk) * 0.9996f, g_k2 ? l.third : l.second) - l.mg;
             l.budget = l.certified ? std::fmax(l.budget, lb) : lb;
         }
         l.steps++;
         st.lane_steps++;
         l.last = l.bid;
+        if (do_walk || g_k2) l.last2 = l.sid;
         if (l.best < mp.eps_hit) { l.hit = true; l.alive = false; }
         else {
             l.t = l.t + l.best;
@@ -249,6 +283,8 @@ int main(int argc, char** argv) {
     int defer = argc > 7 ? atoi(argv[7]) : 0;
     int tw = argc > 8 ? atoi(argv[8]) : 8, th = 64 / tw;
 
+    if (getenv("SIM_EXT")) g_ext = atof(getenv("SIM_EXT"));
+    g_k2 = getenv("SIM_K2") != nullptr;
     sdfhost_node* node = sdfhost_random_scene(n_prims, seed, 0.f, nullptr);
     sdfhost_expanded* ex = sdfhost_expanded_new(node, nullptr);
     sdfhost_buffer* buf = sdfhost_make_buffer(ex, nullptr);
@@ -320,6 +356,7 @@ int main(int argc, char** argv) {
            st.wave_inner, st.wave_leaf, st.lane_steps, st.lane_walks);
     printf("inner/walk %.1f lane_inner/lane_walk %.1f needed/lane_walk %.1f  VALU est %.3fe9\n", (double)st.wave_inner / st.wave_walks,
            (double)st.lane_inner / st.lane_walks, (double)st.lane_needed / st.lane_walks, st.valu() / 1e9);
+    printf("leading single-child chain: %.2f inner visits per walk\n", (double)st.chain_inner / st.wave_walks);
     std::sort(wave_cost.begin(), wave_cost.end());
     printf("waves %zu  max wave VALU %.0f  p99 %.0f  median %.0f\n", wave_cost.size(), wave_cost.back(),
            wave_cost[wave_cost.size() * 99 / 100], wave_cost[wave_cost.size() / 2]);
