@@ -371,6 +371,7 @@ int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOper
     c->tree.bounds = t.info.bounds;
     c->tree.margin_T = t.margin_T;
     c->tree.lipschitz = t.lipschitz;
+    c->tree.box_scale = t.box_scale;
     c->mean_extent = t.mean_extent;
     c->tree.skip_ext = c->skip_ext_opt < 0.f ? 0.5f * t.mean_extent : c->skip_ext_opt;
     c->info = t.info;

@@ -541,6 +541,20 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     }
     out->stack_depth = std::max(1u, depth);
     out->margin_T = margin_T;
+    if (mode != SDFGPU_BOUNDS_OBB && !out->inner.empty()) {
+        // Box records in scaled coordinates (kernels.hip, aabb_dist2): a power of two (exact) that puts
+        // every per-axis distance within 16 scene extents below 1, the range of the hardware result clamp.
+        double ext = 1.0;
+        if (mode != SDFGPU_BOUNDS_NONE)
+            for (int a = 0; a < 3; ++a) ext = std::max({ext, std::fabs(root.lo[a]), std::fabs(root.hi[a])});
+        int e = 0;
+        std::frexp(16.0 * ext, &e);                  // 16 ext < 2^e
+        e = std::min(e, 100);
+        const float sc = std::ldexp(1.0f, -e);
+        out->box_scale = sc;
+        for (GpuInner& g : out->inner)
+            for (int a = 0; a < 3; ++a) { g.c0[a] *= sc; g.h0[a] *= sc; g.c1[a] *= sc; g.h1[a] *= sc; }
+    }
     // budget decrement per unit of march distance: the Lipschitz constant, plus the rounding of the product
     out->lipschitz = round_up(lip * 1.000004);
 

@@ -78,6 +78,7 @@ struct CompactTree {
     uint32_t root_ref = REF_NONE;
     uint32_t stack_depth = 1;           // pending far children never exceed this
     float margin_T = 0.f;               // scene term of the prune margin
+    float box_scale = 1.f;              // power of two the AABB records (GpuInner c/h) are multiplied by (kernels.hip, aabb_dist2)
     float lipschitz = 1.000004f;        // how fast a leaf value can change per unit the point moves (march budget)
     float mean_extent = 0.f;            // mean primitive size (largest parameter), for tuning defaults
     sdfgpu_tree_info info{};

@@ -100,11 +100,17 @@ __device__ __forceinline__ float min_nn(float a, float b) { return a < b ? a : b
 
 // Squared distance to an axis-aligned box (0 inside), box as centre + half
 // extent.  Not exact by design (the prune margin covers its rounding).
+// Boxes and the point are in SCALED coordinates (TreeView::bscale, a power of two chosen at upload
+// so that anything within 16 scene extents is below 1): the per-axis distance max(|p - c| - h, 0)
+// is then one subtraction with the hardware's [0,1] result clamp instead of a subtraction and a
+// max.  Scaling by a power of two is exact, so inside that range the test decides exactly what the
+// unscaled one would; beyond it the clamp only makes the bound smaller, i.e. prunes less.
+__device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.f), 1.f); }
 __device__ __forceinline__ float aabb_dist2(const float* __restrict__ c, const float* __restrict__ h, float px,
                                             float py, float pz) {
-    float dx = __builtin_fmaxf(__builtin_fabsf(px - c[0]) - h[0], 0.f);
-    float dy = __builtin_fmaxf(__builtin_fabsf(py - c[1]) - h[1], 0.f);
-    float dz = __builtin_fmaxf(__builtin_fabsf(pz - c[2]) - h[2], 0.f);
+    float dx = clamp01(__builtin_fabsf(px - c[0]) - h[0]);
+    float dy = clamp01(__builtin_fabsf(py - c[1]) - h[1]);
+    float dz = clamp01(__builtin_fabsf(pz - c[2]) - h[2]);
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
@@ -133,6 +139,8 @@ struct TreeView {
     uint32_t n_leaf;
     float margin_T;
     float skip_ext;     // widening of the search radius that pays for skipped walks (render)
+    float inv_bscale;   // 1 / bscale
+    float bscale;       // AABB modes: power-of-two scale of the boxes (point and threshold are scaled to match)
     float lip;          // max change of any leaf value per unit the point moves, rounded up (1.000004 for rigid leaves)
 };
 
@@ -154,11 +162,11 @@ struct WaveCounters {
 // OBB mode compares MINDIST directly: pruned iff m > 0 && m > best + mg
 // (the reference's test, faux_shader.rs:119-120, plus the margin).
 template <int MODE>
-__device__ __forceinline__ float prune_threshold(float best, float mg, float ext = 0.f) {
+__device__ __forceinline__ float prune_threshold(float best, float mg, float ext, float bscale) {
     if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
         return (best + mg) + ext;
     } else {
-        float bp = __builtin_fmaxf(best + mg, 0.f) + ext;
+        float bp = (__builtin_fmaxf(best + mg, 0.f) + ext) * bscale;   // exact: bscale is a power of two
         return bp * bp * 1.0006f;
     }
 }
@@ -248,7 +256,7 @@ __device__ __forceinline__ void nn_traverse_cxx(const TreeView& T, float px, flo
     const bool mine = (drive >> lane) & 1ull;
     uint32_t sp = 0;
     int refs = 0;  // lane k holds the reference of stack entry k
-    float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+    float thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
     if constexpr (COUNT) wc.lane_queries += mine ? 1u : 0u;
     cur = __builtin_amdgcn_readfirstlane(cur);
 
@@ -267,8 +275,8 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
             const f32x16 N = load_rec64(T.inner, cur);
             const float c0[3] = {N[0], N[1], N[2]}, h0[3] = {N[3], N[4], N[5]};
             const float c1[3] = {N[6], N[7], N[8]}, h1[3] = {N[9], N[10], N[11]};
-            k0 = aabb_dist2(c0, h0, px, py, pz);
-            k1 = aabb_dist2(c1, h1, px, py, pz);
+            k0 = aabb_dist2(c0, h0, px * T.bscale, py * T.bscale, pz * T.bscale);
+            k1 = aabb_dist2(c1, h1, px * T.bscale, py * T.bscale, pz * T.bscale);
             r0 = rec_bits(N[12]);
             r1 = rec_bits(N[13]);
         }
@@ -309,7 +317,7 @@ visit_leaf: {
         const uint32_t id = cur & REF_INDEX;
         const f32x16 L = load_rec64(T.leaf, id);
         acc.offer(leaf_eval_rec(L, px, py, pz), id);
-        thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+        thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
         if constexpr (COUNT) {
             wc.wave_leaf += 1;
             if (rec_bits(L[15]) == SDF_PRIM_SPHERE) wc.lane_sphere += mine ? 1u : 0u;
@@ -359,24 +367,18 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "v_subrev_f32 %[a], s80, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s81, %[py]\n\t"                                                              \
     "v_subrev_f32 %[c], s82, %[pz]\n\t"                                                              \
-    "v_sub_f32 %[a], |%[a]|, s83\n\t"                                                                \
-    "v_sub_f32 %[b], |%[b]|, s84\n\t"                                                                \
-    "v_sub_f32 %[c], |%[c]|, s85\n\t"                                                                \
-    "v_max_f32 %[a], 0, %[a]\n\t"                                                                    \
-    "v_max_f32 %[b], 0, %[b]\n\t"                                                                    \
-    "v_max_f32 %[c], 0, %[c]\n\t"                                                                    \
+    "v_sub_f32 %[a], |%[a]|, s83 clamp\n\t"                                                          \
+    "v_sub_f32 %[b], |%[b]|, s84 clamp\n\t"                                                          \
+    "v_sub_f32 %[c], |%[c]|, s85 clamp\n\t"                                                          \
     "v_mul_f32 %[k0], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k0], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k0], %[c], %[c]\n\t"                                                               \
     "v_subrev_f32 %[a], s86, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s87, %[py]\n\t"                                                              \
     "v_subrev_f32 %[c], s88, %[pz]\n\t"                                                              \
-    "v_sub_f32 %[a], |%[a]|, s89\n\t"                                                                \
-    "v_sub_f32 %[b], |%[b]|, s90\n\t"                                                                \
-    "v_sub_f32 %[c], |%[c]|, s91\n\t"                                                                \
-    "v_max_f32 %[a], 0, %[a]\n\t"                                                                    \
-    "v_max_f32 %[b], 0, %[b]\n\t"                                                                    \
-    "v_max_f32 %[c], 0, %[c]\n\t"                                                                    \
+    "v_sub_f32 %[a], |%[a]|, s89 clamp\n\t"                                                          \
+    "v_sub_f32 %[b], |%[b]|, s90 clamp\n\t"                                                          \
+    "v_sub_f32 %[c], |%[c]|, s91 clamp\n\t"                                                          \
     "v_mul_f32 %[k1], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k1], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k1], %[c], %[c]\n\t"                                                               \
@@ -498,18 +500,19 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
     int refs = 0;   // lane k holds the reference of stack entry k
     float lb = __builtin_inff();
     if constexpr (Acc::TRACKS) lb = acc.lb_key;
-    float thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+    float thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
     // LDS byte address of this lane's slot in stack level 0; level l is 256 bytes further
     const uint32_t sa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)stk + lane * 4u;
+    const float sx = px * T.bscale, sy = py * T.bscale, sz = pz * T.bscale;   // the boxes' coordinates
     for (;;) {
         f32x16 L;   // the leaf's record, fetched inside the block (undefined when the walk is over)
-        walk_advance<Acc::TRACKS>(cur, sp, refs, lb, thr, px, py, pz, drive, T.inner, T.leaf, sa, L);
+        walk_advance<Acc::TRACKS>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L);
         cur = __builtin_amdgcn_readfirstlane(cur);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (cur == REF_NONE) break;
         const uint32_t id = cur & REF_INDEX;
         acc.offer(leaf_eval_rec(L, px, py, pz), id);
-        thr = prune_threshold<MODE>(acc.radius(), mg, ext);
+        thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
         cur = REF_POP;
     }
     if constexpr (Acc::TRACKS) acc.lb_key = lb;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
             best = acc.best;
             bid = acc.bid;
             // a bound, not a result: the hardware square root (1 ulp) is inside the 0.9996
-            float lb = (MODE == SDFGPU_BOUNDS_OBB) ? acc.lb_key : __builtin_amdgcn_sqrtf(acc.lb_key);
+            float lb = (MODE == SDFGPU_BOUNDS_OBB) ? acc.lb_key : __builtin_amdgcn_sqrtf(acc.lb_key) * T.inv_bscale;
             lb = __builtin_fminf(lb * 0.9996f, acc.second) - mg;
             // only for the lanes the walk was for: a lane that has finished this pass's steps keeps the
             // budget it carries to the next pass (the walk saw the point it stopped at, not its next one)
@@ -1163,6 +1166,8 @@ static TreeView make_view(const DeviceTree& d) {
     v.n_leaf = d.n_leaf;
     v.skip_ext = d.skip_ext;
     v.lip = d.lipschitz;
+    v.bscale = d.box_scale;
+    v.inv_bscale = 1.0f / d.box_scale;
     return v;
 }
 

@@ -22,6 +22,7 @@ struct DeviceTree {
     float margin_T = 0.f;
     float skip_ext = 0.f;
     float lipschitz = 1.000004f;
+    float box_scale = 1.f;
 };
 
 // st != nullptr selects the counting instantiation of the same kernel.

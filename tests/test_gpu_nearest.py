@@ -67,9 +67,15 @@ def test_points_inside_primitives_and_far_away(gpu):
     L = S.default_extent(200)
     near = make_points(4096, L, seed=3, scale=0.3)      # many inside / close
     far = make_points(4096, L, seed=4, scale=40.0)      # far outside the scene
-    for b in (S.BOUNDS_AABB, S.BOUNDS_OBB):
+    # beyond 16 scene extents the box test's [0,1] result clamp saturates (kernels.hip, aabb_dist2):
+    # the bound only gets looser there, results must not change
+    very_far = make_points(1024, L, seed=5, scale=3000.0)
+    huge = make_points(256, L, seed=6, scale=1e12)
+    for b in (S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_BVH):
         _check(gpu, buf, near, b)
         _check(gpu, buf, far, b)
+        _check(gpu, buf, very_far, b)
+        _check(gpu, buf, huge, b)
 
 
 def test_duplicate_primitive_tie_goes_to_later(gpu):
