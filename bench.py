@@ -147,6 +147,20 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
         t = torch.tensor([el1], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el1 = float(t.item())
+    def timed(fn):
+        fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.knn_steps):
+            fn()
+        barrier()
+        e = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([e], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        return e
+
     out = {
         "metric": "kNN queries/s (k=8)", "value": n_total * a.knn_steps / el, "unit": "queries/s",
         "nearest_k1": {"value": n_total * a.knn_steps / el1, "unit": "queries/s", "ms_per_step": el1 / a.knn_steps * 1e3},
@@ -156,20 +170,74 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
                    "points": "uniform in 1.2x the scene cube, unsorted (Morton-reordered inside the call)",
                    "partition": "contiguous query slices, results sharded"},
     }
+    # the same batch handed over already Morton-sorted by the caller -- with the library's own
+    # reordering still on (it sorts a sorted batch) and with it off (the walk alone: no permutation traffic)
+    pts_sorted = torch.from_numpy(W.query_points(wl, n_total, morton=True)[lo:hi]).to(dev)
+    step_s = lambda: gpu.knn_dev(pts_sorted.data_ptr(), n, k, d_out.data_ptr(), i_out.data_ptr(), stream)  # noqa: E731
+    step1_s = lambda: gpu.nearest_dev(pts_sorted.data_ptr(), n, d_out.data_ptr(), i_out.data_ptr(), stream)  # noqa: E731
+    e_on, e1_on = timed(step_s), timed(step1_s)
+    gpu.set_reorder(False)
+    e_off, e1_off = timed(step_s), timed(step1_s)
+    gpu.set_reorder(True)
+    out["presorted"] = {
+        "points": "the same points, Morton-sorted by the caller before the call",
+        "k8_reorder_on": {"value": n_total * a.knn_steps / e_on, "ms_per_step": e_on / a.knn_steps * 1e3},
+        "k8_reorder_off": {"value": n_total * a.knn_steps / e_off, "ms_per_step": e_off / a.knn_steps * 1e3},
+        "k1_reorder_on": {"value": n_total * a.knn_steps / e1_on, "ms_per_step": e1_on / a.knn_steps * 1e3},
+        "k1_reorder_off": {"value": n_total * a.knn_steps / e1_off, "ms_per_step": e1_off / a.knn_steps * 1e3},
+        "unit": "queries/s",
+    }
+    if rank == 0 and world == 1:
+        # roofline of the kNN kernel: units from the counting instantiation, duration from HIP events
+        # around isolated launches with the permutation already made (the kernel alone)
+        st = gpu.knn_stats_dev(pts.data_ptr(), n, k)
+        kms = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            torch.cuda.synchronize()
+            kms.append(e0.elapsed_time(e1))
+        call_ms = float(np.mean(kms))
+        tr, trn = profiled_traffic("knn_kernel<1, 8")
+        out["roofline"] = roofline_object(st, call_ms, "sdfgpu::knn_kernel<1, 8, false>", n * 16 + n * k * 8 + int(info.device_bytes),
+                                          note="kernel_ms_avg = the whole sdfgpu_knn_dev call (Morton keys + radix sort + walk) under HIP "
+                                               "events, so the kernel's own rate is higher (profiles/ has its rocprofv3 duration); fp32 "
+                                               "VALU-bound walk, K-slot insertion counted as 2 flops per offered primitive",
+                                          traffic=tr, traffic_note=trn)
+        out["work"] = {"inner_visits_per_query": st["inner_visits"] / max(1, st["queries"]),
+                       "inner_needed_per_query": st["inner_needed"] / max(1, st["queries"]),
+                       "leaf_evals_per_query": (st["sphere_evals"] + st["box_evals"]) / max(1, st["queries"]),
+                       "leaf_needed_per_query": (st["sphere_needed"] + st["box_needed"]) / max(1, st["queries"]),
+                       "wave_inner_visits": st["wave_inner"], "wave_leaf_visits": st["wave_leaf"]}
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import oracle as O
         threads = max(1, min(O.hardware_threads(), len(os.sched_getaffinity(0))))
-        m = 20000
-        t0 = time.perf_counter()
-        O.nearest(buf, pts_all[:m], O.MODE_TUNED, threads=threads)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline_nearest"] = {"value": m / tc, "unit": "queries/s (k=1, tuned port)", "cores": threads,
-                                       "kind": "port", "sample": f"{m} of the same points, {tc:.2f} s"}
+
+        def cpu_knn(nthreads, budget_s):
+            m = 2000
+            t0 = time.perf_counter()
+            O.knn(buf, pts_all[:m], k, threads=nthreads)
+            tp = time.perf_counter() - t0
+            m = int(min(n_total, max(m, m / max(tp, 1e-6) * budget_s)))
+            t0 = time.perf_counter()
+            O.knn(buf, pts_all[:m], k, threads=nthreads)
+            tc = time.perf_counter() - t0
+            return m, tc
+
+        m1, t1c = cpu_knn(1, 3.0)
+        mN, tNc = cpu_knn(threads, 4.0)
+        out["cpu_baseline"] = {"value": mN / tNc, "unit": "queries/s", "cores": threads, "kind": "port",
+                               "sample": f"k=8, {mN} of the same points, oracle_knn (C++ restatement, best-so-far pruning), "
+                                         f"{threads} threads, {tNc:.2f} s",
+                               "one_thread_value": m1 / t1c,
+                               "one_thread_sample": f"k=8, {m1} of the same points, 1 thread, {t1c:.2f} s"}
     gpu.close()
     return out
 
 
-def profiled_traffic():
+def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true>"):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE are collected in separate runs by tools/profile_bench.sh;
     bench.py itself cannot read counters).  FETCH_SIZE/WRITE_SIZE are in KiB; the reads of
@@ -185,11 +253,104 @@ def profiled_traffic():
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if "render_pass_kernel<1, false, true>" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            if kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 best = (path, (v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0)
     if best is None:
         return None, "no PMC profile committed"
     return best[1], "bytes per launch, FETCH_SIZE + WRITE_SIZE from " + os.path.relpath(best[0], os.path.dirname(os.path.abspath(__file__)))
+
+
+def roofline_object(st, kernel_ms, kernel_name, bytes_alg, note, traffic=None, traffic_note=None):
+    """The `roofline` object of the JSON line for a VALU-bound walk kernel.  `achieved` counts the units
+    a lane itself needed (its own bound asked for the node / primitive); `achieved_issued` also counts the
+    lanes that only rode along on a node their wavefront visited for somebody else."""
+    f_need, f_issued = W.algorithmic_flops_needed(st), W.algorithmic_flops(st)
+    t = kernel_ms * 1e-3
+    ach = f_need / t / 1e12
+    return {
+        "bound": "valu",
+        "achieved": ach,
+        "peak": VALU_PEAK_FMA_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": ach / VALU_PEAK_FMA_TFLOPS,
+        "traffic": traffic,
+        "traffic_note": traffic_note,
+        "kernel": kernel_name,
+        "kernel_ms_avg": kernel_ms,
+        "algorithmic_flops_per_launch": f_need,
+        "peak_note": "157.3 = MI355X_MICROARCH.md peak fp32 vector (FMA counted as 2); leaf arithmetic must stay unfused "
+                     "for bit parity, so one rounded op per lane-issue = 78.6 TFLOP/s is the ceiling this code can approach",
+        "frac_of_unfused_peak": ach / VALU_PEAK_UNFUSED_TFLOPS,
+        "achieved_issued": f_issued / t / 1e12,
+        "frac_issued": f_issued / t / 1e12 / VALU_PEAK_FMA_TFLOPS,
+        "lane_utility": f_need / max(1, f_issued),
+        "hbm": {"algorithmic_bytes_per_launch": bytes_alg, "achieved_GBs": bytes_alg / t / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                "frac": bytes_alg / t / 1e9 / HBM_PEAK_GBS},
+        "note": note,
+    }
+
+
+def variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev):
+    """The same frame under the conditions the headline does not cover (N = 1, outside the timed region):
+    strictly one frame after the other, a moving camera (the learned tile order is always stale), tile
+    ordering off, the very first frame of a fresh context, and tree upload times."""
+    import math
+    npix = w * h
+
+    def run(step, frames):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for kk in range(frames):
+            step(kk)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / frames * 1e3
+
+    def frame(g, c, sl):
+        g.render_dev(c, w, h, mp, sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(), sl.o_prim.data_ptr(),
+                     sl.stream.cuda_stream)
+
+    out = {}
+    frames = max(4, a.steps)
+    ms1 = run(lambda kk: frame(gpu, cam, slots[0]), frames)
+    out["pipeline1"] = {"value": npix / ms1 / 1e3, "ms_per_step": ms1, "note": "one frame in flight, one stream"}
+    L = S.default_extent(wl.n_prims)
+    cams = [S.camera_look_at((2.5 * L * math.sin(0.02 * i), 0.0, -2.5 * L * math.cos(0.02 * i)), (0, 0, 0), (0, 1, 0),
+                             math.pi / 4, w, h) for i in range(frames)]
+    msm = run(lambda kk: frame(gpu, cams[kk], slots[kk % depth]), frames)
+    out["moving_camera"] = {"value": npix / msm / 1e3, "ms_per_step": msm,
+                            "note": f"orbit, 0.02 rad per frame, {depth} frames in flight; tile order learned from a different view"}
+    gpu.set_tile_order(False)
+    mso = run(lambda kk: frame(gpu, cam, slots[kk % depth]), frames)
+    gpu.set_tile_order(not a.no_tile_order)
+    out["tile_order_off"] = {"value": npix / mso / 1e3, "ms_per_step": mso, "note": f"tiles in raster order, {depth} frames in flight"}
+    # cold: fresh context, tree just uploaded, first frame (no schedule, buffers of the context untouched)
+    g2 = S.SdfGpu(dev.index)
+    buf = W.scene(wl)
+    t0 = time.perf_counter()
+    g2.upload_tree(buf)
+    up = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frame(g2, cam, slots[0])
+    torch.cuda.synchronize()
+    out["cold_frame_ms"] = (time.perf_counter() - t0) * 1e3
+    g2.close()
+    # tree flatten (host builder's make_buffer) and upload (validate + SAH build + copy), per scene size
+    out["upload_ms"] = {}
+    for cfg in (2, 3, 4):
+        wlx = W.CONFIGS[cfg]
+        node = S.random_scene(wlx.n_prims, wlx.seed)
+        t0 = time.perf_counter()
+        b = node.expanded().make_buffer()
+        fl = (time.perf_counter() - t0) * 1e3
+        g3 = S.SdfGpu(dev.index)
+        t0 = time.perf_counter()
+        g3.upload_tree(b)
+        torch.cuda.synchronize()
+        upx = (time.perf_counter() - t0) * 1e3
+        g3.close()
+        out["upload_ms"][f"{wlx.n_prims}_prims"] = {"flatten_expanded_make_buffer_ms": fl, "sdfgpu_upload_tree_ms": upx}
+    return out
 
 
 def trace(msg):
@@ -382,6 +543,8 @@ def main():
                 "max_steps": int(mp.max_steps), "eps_hit": float(mp.eps_hit), "t_max": float(mp.t_max),
                 "normal_h": float(mp.normal_h),
                 "frames_in_flight": depth,
+                "tile_order": not a.no_tile_order,
+                "camera": "static (every frame the same view; the longest-first tile order is learned from the previous frame)",
                 "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL all-gather",
                 "hit_fraction": hit_frac,
                 "assembly_check": assembly_check,
@@ -390,35 +553,14 @@ def main():
         if world == 1:
             k_avg = float(np.mean(kms))
             st = gpu.render_stats(cam, w, h, mp)
-            flops = W.algorithmic_flops(st)
-            achieved = flops / (k_avg * 1e-3) / 1e12
             bytes_alg = npix * 21 + int(info.device_bytes)
             traffic, traffic_note = profiled_traffic()
-            line["roofline"] = {
-                "bound": "valu",
-                "achieved": achieved,
-                "peak": VALU_PEAK_UNFUSED_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / VALU_PEAK_UNFUSED_TFLOPS,
-                "traffic": traffic,
-                "traffic_note": traffic_note,
-                "kernel": "sdfgpu::render_pass_kernel<1, false, true>",
-                "kernel_ms_avg": k_avg,
-                "algorithmic_flops_per_launch": flops,
-                "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS,
-                # tools/ubench/issue_rates.hip: a SIMD retires one plain fp32 VALU instruction per ~2.6
-                # cycles with 8 waves resident, i.e. 60.5 Tflop/s of unfused operations chip-wide
-                "frac_of_measured_issue_peak": achieved / 60.5,
-                # the same flops over the pipelined frame time (frames in flight fill the drain)
-                "frac_at_throughput": flops / (ms * 1e-3) / 1e12 / VALU_PEAK_UNFUSED_TFLOPS,
-                "hbm": {"algorithmic_bytes_per_launch": bytes_alg,
-                        "achieved_GBs": bytes_alg / (k_avg * 1e-3) / 1e9,
-                        "peak_GBs": HBM_PEAK_GBS,
-                        "frac": bytes_alg / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "note": "fp32 VALU-bound tree walk, no dense contraction (no MFMA); leaf arithmetic must stay "
-                        "unfused for bit parity so the ceiling is one op per lane-issue (78.6 TFLOP/s), not the "
-                        "157.3 TFLOP/s FMA figure",
-            }
+            line["roofline"] = roofline_object(
+                st, k_avg, "sdfgpu::render_pass_kernel<1, false, true>", bytes_alg,
+                note="fp32 VALU-bound tree walk, no dense contraction (no MFMA); kernel_ms_avg = isolated launches under "
+                     "HIP events on the launch stream, outside the timed region",
+                traffic=traffic, traffic_note=traffic_note)
+            line["roofline"]["frac_at_throughput"] = W.algorithmic_flops_needed(st) / (ms * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS
             line["work"] = {
                 "steps_per_ray": st["steps"] / max(1, st["rays"]),
                 "walks_per_ray": st["queries"] / max(1, st["rays"]),
@@ -426,9 +568,12 @@ def main():
                 "inner_visits_per_walk": st["inner_visits"] / max(1, st["queries"]),
                 "inner_needed_per_walk": st["inner_needed"] / max(1, st["queries"]),
                 "leaf_evals_per_step": (st["sphere_evals"] + st["box_evals"]) / max(1, st["steps"]),
+                "leaf_needed_per_step": (st["sphere_needed"] + st["box_needed"]) / max(1, st["steps"]),
                 "wave_inner_visits": st["wave_inner"], "wave_leaf_visits": st["wave_leaf"],
                 "queries": st["queries"],
+                "needed_over_issued_lane_slots": st["inner_needed"] / max(1, 64 * st["wave_inner"]),
             }
+            line["variants"] = variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev)
             if not a.no_cpu:
                 line["cpu_baseline"] = cpu_baseline(buf, cam, mp, w, h, a.cpu_seconds)
     knn = None

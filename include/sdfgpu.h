@@ -116,6 +116,8 @@ typedef struct sdfgpu_stats {
     uint64_t wave_steps;     /* march steps per wavefront */
     uint64_t wave_walks;     /* ... of which needed a tree walk (the rest were proven by kept bounds) */
     uint64_t inner_needed;   /* internal-node visits a lane itself needed (<= inner_visits: the wave visits the union) */
+    uint64_t sphere_needed;  /* primitive evaluations a lane itself needed: seeds, and leaves its own bound asked for */
+    uint64_t box_needed;
 } sdfgpu_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -261,6 +263,8 @@ int sdfgpu_render_stats(sdfgpu_ctx* ctx, const sdfgpu_camera* cam, uint32_t widt
                         sdfgpu_stats* out);
 int sdfgpu_nearest_stats_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n,
                              sdfgpu_stats* out);
+int sdfgpu_knn_stats_dev(sdfgpu_ctx* ctx, const float* d_pts_xyzw, size_t n, uint32_t k,
+                         sdfgpu_stats* out);
 
 /* Host helper: fill a sdfgpu_camera for a pinhole at `eye` looking at
  * `target` (geometry of src/main__.rs:261-264), vertical field of view

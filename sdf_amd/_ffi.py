@@ -108,6 +108,8 @@ class Stats(C.Structure):
         ("wave_steps", C.c_uint64),
         ("wave_walks", C.c_uint64),
         ("inner_needed", C.c_uint64),
+        ("sphere_needed", C.c_uint64),
+        ("box_needed", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -152,6 +154,7 @@ GPU_SYMBOLS = {
     "sdfgpu_untile_dev": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdfgpu_render_stats": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), C.POINTER(Stats)]),
     "sdfgpu_nearest_stats_dev": (_i, [_vp, _vp, _sz, C.POINTER(Stats)]),
+    "sdfgpu_knn_stats_dev": (_i, [_vp, _vp, _sz, _u32, C.POINTER(Stats)]),
     "sdfgpu_camera_look_at": (None, [_fp, _fp, _fp, _f, _u32, _u32, C.POINTER(Camera)]),
 }
 

@@ -458,6 +458,27 @@ int sdfgpu_nearest_stats_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, sdfgpu
     return SDFGPU_OK;
 }
 
+int sdfgpu_knn_stats_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, uint32_t k, sdfgpu_stats* out) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!out) return SDFGPU_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    if (k == 0 || k > SDFGPU_MAX_K) return set_err(c, SDFGPU_ERR_TOO_LARGE, "k must be in 1..SDFGPU_MAX_K (16)");
+    if (n == 0) return SDFGPU_OK;
+    if (n > 0x7FFFFFFFull / k) return set_err(c, SDFGPU_ERR_TOO_LARGE, "n * k exceeds 2^31-1 in one call");
+    if ((rc = reserve(c, c->stats, sizeof(sdfgpu_stats))) || (rc = reserve(c, c->out_a, n * k * 4)) ||
+        (rc = reserve(c, c->out_b, n * k * 4)))
+        return rc;
+    HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, sizeof(sdfgpu_stats), c->stream));
+    const uint32_t* order = nullptr;
+    if ((rc = make_order(c, d_pts, n, c->stream, &order))) return rc;
+    HIP_TRY(c, launch_knn(c->tree, d_pts, order, (uint32_t)n, k, (float*)c->out_a.p, (uint32_t*)c->out_b.p,
+                          (sdfgpu_stats*)c->stats.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDFGPU_OK;
+}
+
 int sdfgpu_set_option(sdfgpu_ctx* c, int option, double value) {
     if (!c) return SDFGPU_ERR_INVALID_ARG;
     switch (option) {
@@ -490,7 +511,7 @@ int sdfgpu_knn_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, uint32_t k, floa
     if (n > 0x7FFFFFFFull / k) return set_err(c, SDFGPU_ERR_TOO_LARGE, "n * k exceeds 2^31-1 in one call");
     const uint32_t* order = nullptr;
     if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order))) return rc;
-    HIP_TRY(c, launch_knn(c->tree, d_pts, order, (uint32_t)n, k, d_dist, d_prim, (hipStream_t)stream));
+    HIP_TRY(c, launch_knn(c->tree, d_pts, order, (uint32_t)n, k, d_dist, d_prim, nullptr, (hipStream_t)stream));
     return SDFGPU_OK;
 }
 

@@ -155,6 +155,7 @@ __device__ __forceinline__ float prune_margin(const TreeView& T, float px, float
 struct WaveCounters {
     uint32_t wave_inner = 0, wave_leaf = 0, wave_steps = 0, wave_walks = 0;
     uint32_t lane_inner = 0, lane_sphere = 0, lane_box = 0, lane_queries = 0, lane_needed = 0;
+    uint32_t lane_sphere_needed = 0, lane_box_needed = 0;   // ... of which the lane's own bound asked for
 };
 
 // Prune threshold for the current best.  AABB mode compares squared
@@ -259,6 +260,7 @@ __device__ __forceinline__ void nn_traverse_cxx(const TreeView& T, float px, flo
     float thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
     if constexpr (COUNT) wc.lane_queries += mine ? 1u : 0u;
     cur = __builtin_amdgcn_readfirstlane(cur);
+    float kcur = 0.f;   // COUNT: this lane's bound key of the node being visited (the root is always needed)
 
 top:   // single loop header (keeps the control flow reducible): cur is a valid reference
     if (cur & REF_LEAF) goto visit_leaf;
@@ -298,9 +300,11 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
                 refs = (lane == sp) ? (int)(first0 ? r1 : r0) : refs;   // v_writelane has no builtin here
                 sp += 1;
                 cur = first0 ? r0 : r1;
+                kcur = first0 ? k0 : k1;
             } else {
                 acc.skipped(k1);
                 cur = r0;
+                kcur = k0;
             }
         } else {
             acc.skipped(k0);
@@ -309,6 +313,7 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
                 goto pop;
             }
             cur = r1;
+            kcur = k1;
         }
         goto top;
     }
@@ -316,12 +321,14 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
 visit_leaf: {
         const uint32_t id = cur & REF_INDEX;
         const f32x16 L = load_rec64(T.leaf, id);
+        const float thr_before = thr;
         acc.offer(leaf_eval_rec(L, px, py, pz), id);
         thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
         if constexpr (COUNT) {
             wc.wave_leaf += 1;
-            if (rec_bits(L[15]) == SDF_PRIM_SPHERE) wc.lane_sphere += mine ? 1u : 0u;
-            else wc.lane_box += mine ? 1u : 0u;
+            const uint32_t want = (mine && needed<MODE>(kcur, thr_before)) ? 1u : 0u;
+            if (rec_bits(L[15]) == SDF_PRIM_SPHERE) { wc.lane_sphere += mine ? 1u : 0u; wc.lane_sphere_needed += want; }
+            else { wc.lane_box += mine ? 1u : 0u; wc.lane_box_needed += want; }
         }
     }
 
@@ -334,6 +341,7 @@ pop:
         acc.skipped(k);
     }
     cur = (uint32_t)__builtin_amdgcn_readlane(refs, sp);
+    kcur = stk[sp * 64u + lane];
     goto top;
 }
 
@@ -529,9 +537,10 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
                                                sdfgpu_stats* st) {
     // wave-reduce the per-lane counters, one atomic per counter per wave
-    uint32_t v[7] = {wc.lane_queries, wc.lane_inner, wc.lane_sphere, wc.lane_box, steps, rays, wc.lane_needed};
+    uint32_t v[9] = {wc.lane_queries, wc.lane_inner, wc.lane_sphere, wc.lane_box, steps, rays, wc.lane_needed,
+                     wc.lane_sphere_needed, wc.lane_box_needed};
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 9; ++i)
         for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
     if (lane == 0) {
         atomicAdd((unsigned long long*)&st->queries, (unsigned long long)v[0]);
@@ -541,6 +550,8 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
         atomicAdd((unsigned long long*)&st->steps, (unsigned long long)v[4]);
         atomicAdd((unsigned long long*)&st->rays, (unsigned long long)v[5]);
         atomicAdd((unsigned long long*)&st->inner_needed, (unsigned long long)v[6]);
+        atomicAdd((unsigned long long*)&st->sphere_needed, (unsigned long long)v[7]);
+        atomicAdd((unsigned long long*)&st->box_needed, (unsigned long long)v[8]);
         atomicAdd((unsigned long long*)&st->wave_inner, (unsigned long long)wc.wave_inner);
         atomicAdd((unsigned long long*)&st->wave_leaf, (unsigned long long)wc.wave_leaf);
         atomicAdd((unsigned long long*)&st->wave_steps, (unsigned long long)wc.wave_steps);
@@ -630,10 +641,11 @@ struct AccK {
     }
 };
 
-template <int MODE, int K>
+template <int MODE, int K, bool COUNT>
 __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __restrict__ pts,
                                                   const uint32_t* __restrict__ order, uint32_t n, uint32_t k,
-                                                  float* __restrict__ out_dist, uint32_t* __restrict__ out_prim) {
+                                                  float* __restrict__ out_dist, uint32_t* __restrict__ out_prim,
+                                                  sdfgpu_stats* __restrict__ st) {
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* __restrict__ stk = smem + wave * T.depth * 64u;
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     AccK<K> acc;
     acc.init();
     WaveCounters wc;
-    nn_traverse<MODE, false>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
+    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
     if (alive) {
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -654,6 +666,7 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
                 out_prim[(size_t)src * k + j] = acc.prim(j);
             }
     }
+    if constexpr (COUNT) flush_counters(wc, lane, 0, 0, st);
 }
 
 // ------------------------------------------------- K3 + K4: march, normal --
@@ -835,7 +848,8 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         }
         if constexpr (COUNT) {
             if (adv & seeded) {   // the seed evaluation of this step
-                if (__builtin_bit_cast(uint32_t, c3.w) == SDF_PRIM_SPHERE) wc.lane_sphere += 1; else wc.lane_box += 1;
+                if (__builtin_bit_cast(uint32_t, c3.w) == SDF_PRIM_SPHERE) { wc.lane_sphere += 1; wc.lane_sphere_needed += 1; }
+                else { wc.lane_box += 1; wc.lane_box_needed += 1; }
             }
         }
         const bool hit_now = adv & (best < mp.eps_hit);
@@ -1208,25 +1222,25 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t*
 }
 
 
-template <int MODE>
+template <int MODE, bool COUNT>
 static hipError_t launch_knn_m(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, uint32_t k,
-                               float* out_dist, uint32_t* out_prim, hipStream_t s) {
+                               float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     TreeView v = make_view(d);
     const uint32_t wpg = wg_waves();
     dim3 grid((n + 64u * wpg - 1u) / (64u * wpg)), block(64u * wpg);
     size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
     const float4* p4 = (const float4*)pts;
-    if (k <= 2) knn_kernel<MODE, 2><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
-    else if (k <= 4) knn_kernel<MODE, 4><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
-    else if (k <= 8) knn_kernel<MODE, 8><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
-    else knn_kernel<MODE, 16><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim);
+    if (k <= 2) knn_kernel<MODE, 2, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    else if (k <= 4) knn_kernel<MODE, 4, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    else if (k <= 8) knn_kernel<MODE, 8, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    else knn_kernel<MODE, 16, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
     return hipGetLastError();
 }
 
 hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, uint32_t k,
-                      float* out_dist, uint32_t* out_prim, hipStream_t s) {
+                      float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     if (n == 0 || k == 0) return hipSuccess;
-    if (d.gen) {
+    if (d.gen) {   // general path: exhaustive literal chain, no counters
         dim3 grid((n + 63u) / 64u), block(64);
         const size_t lds = general_lds(d);
         const float4* p4 = (const float4*)pts;
@@ -1236,8 +1250,11 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
         else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
         return hipGetLastError();
     }
-    return d.bounds == SDFGPU_BOUNDS_OBB ? launch_knn_m<SDFGPU_BOUNDS_OBB>(d, pts, order, n, k, out_dist, out_prim, s)
-                                         : launch_knn_m<SDFGPU_BOUNDS_AABB>(d, pts, order, n, k, out_dist, out_prim, s);
+    const bool obb = d.bounds == SDFGPU_BOUNDS_OBB;
+    if (st) return obb ? launch_knn_m<SDFGPU_BOUNDS_OBB, true>(d, pts, order, n, k, out_dist, out_prim, st, s)
+                       : launch_knn_m<SDFGPU_BOUNDS_AABB, true>(d, pts, order, n, k, out_dist, out_prim, st, s);
+    return obb ? launch_knn_m<SDFGPU_BOUNDS_OBB, false>(d, pts, order, n, k, out_dist, out_prim, nullptr, s)
+               : launch_knn_m<SDFGPU_BOUNDS_AABB, false>(d, pts, order, n, k, out_dist, out_prim, nullptr, s);
 }
 
 template <int MODE, bool COUNT>

@@ -31,7 +31,7 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts_xyzw, const uint
 
 // k nearest (k <= SDFGPU_MAX_K): out[i*k + j], ascending by (distance, larger index first).
 hipError_t launch_knn(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n, uint32_t k,
-                      float* out_dist, uint32_t* out_prim, hipStream_t s);
+                      float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s);
 
 // Morton order of a query batch inside [lo, hi): idx_out = permutation (sort.hip).
 size_t sort_temp_bytes(uint32_t n);

@@ -108,6 +108,11 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_nearest_stats_dev(self._h, d_pts, n, C.byref(st)))
         return st.as_dict()
 
+    def knn_stats_dev(self, d_pts, n, k):
+        st = _ffi.Stats()
+        self._check(self._lib.sdfgpu_knn_stats_dev(self._h, d_pts, n, k, C.byref(st)))
+        return st.as_dict()
+
     def set_option(self, option, value):
         self._check(self._lib.sdfgpu_set_option(self._h, option, float(value)))
 

@@ -90,3 +90,12 @@ def algorithmic_flops(stats: dict) -> int:
     per_step = max(stats["steps"], stats["queries"])   # render: every march step; nearest: every query
     return (stats["inner_visits"] * FLOP_INNER + stats["sphere_evals"] * FLOP_SPHERE
             + stats["box_evals"] * FLOP_BOX + per_step * FLOP_QUERY)
+
+
+def algorithmic_flops_needed(stats: dict) -> int:
+    """The same count restricted to the units a lane itself needed: internal nodes its own bound asked
+    for, seed evaluations, leaves its own bound asked for (the wavefront visits the union of what its
+    lanes need; lanes that only ride along are not counted here)."""
+    per_step = max(stats["steps"], stats["queries"])
+    return (stats["inner_needed"] * FLOP_INNER + stats["sphere_needed"] * FLOP_SPHERE
+            + stats["box_needed"] * FLOP_BOX + per_step * FLOP_QUERY)

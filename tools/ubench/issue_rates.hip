@@ -69,6 +69,32 @@ __global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) 
                 : "=&v"(k0), "=&v"(k1), "=&v"(ta), "=&v"(tb), "=&v"(tc)
                 : "v"(a0), "v"(a1), "v"(a2), "s"(s0), "s"(s1), "s"(s2) : "vcc");
             a3 += k0 + k1;
+        } else if constexpr (KIND == 11) {  // the box test with the [0,1] result clamp: 18 VALU + 2 compares
+            float k0, k1, ta, tb, tc;
+            asm volatile(
+                "v_subrev_f32 %2, %8, %5\n v_subrev_f32 %3, %9, %6\n v_subrev_f32 %4, %10, %7\n"
+                "v_sub_f32 %2, |%2|, %9 clamp\n v_sub_f32 %3, |%3|, %10 clamp\n v_sub_f32 %4, |%4|, %8 clamp\n"
+                "v_mul_f32 %0, %2, %2\n v_fmac_f32 %0, %3, %3\n v_fmac_f32 %0, %4, %4\n"
+                "v_subrev_f32 %2, %10, %5\n v_subrev_f32 %3, %8, %6\n v_subrev_f32 %4, %9, %7\n"
+                "v_sub_f32 %2, |%2|, %8 clamp\n v_sub_f32 %3, |%3|, %9 clamp\n v_sub_f32 %4, |%4|, %10 clamp\n"
+                "v_mul_f32 %1, %2, %2\n v_fmac_f32 %1, %3, %3\n v_fmac_f32 %1, %4, %4\n"
+                "v_cmp_le_f32 vcc, %0, %5\n v_cmp_le_f32 vcc, %1, %5\n"
+                : "=&v"(k0), "=&v"(k1), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+                : "v"(a0), "v"(a1), "v"(a2), "s"(s0), "s"(s1), "s"(s2) : "vcc");
+            a3 += k0 + k1;
+        } else if constexpr (KIND == 12) {  // 32 packed f16 ops (add / max / mul / fma), VGPR operands
+            unsigned h0 = __float_as_uint(a0), h1 = __float_as_uint(a1), h2 = __float_as_uint(a2), h3 = __float_as_uint(a3);
+            REP8(asm volatile("v_pk_add_f16 %0, %0, %1\n v_pk_max_f16 %2, %2, %1\n v_pk_mul_f16 %3, %3, %1\n v_pk_fma_f16 %1, %1, %0, %2"
+                              : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : );)
+            a0 += __uint_as_float(h0 ^ h1 ^ h2 ^ h3);
+        } else if constexpr (KIND == 13) {  // 32 packed f16 ops with an SGPR operand
+            unsigned h0 = __float_as_uint(a0), h1 = __float_as_uint(a1), h2 = __float_as_uint(a2), h3 = __float_as_uint(a3);
+            REP8(asm volatile("v_pk_add_f16 %0, %0, %4\n v_pk_max_f16 %2, %2, %5\n v_pk_mul_f16 %3, %3, %4\n v_pk_fma_f16 %1, %1, %0, %5"
+                              : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "s"(s0), "s"(s1));)
+            a0 += __uint_as_float(h0 ^ h1 ^ h2 ^ h3);
+        } else if constexpr (KIND == 14) {  // 32 VALU with an SGPR operand and abs (VOP3)
+            REP8(asm volatile("v_sub_f32 %0, |%0|, %5\n v_sub_f32 %2, |%2|, %6\n v_sub_f32 %3, |%3|, %5\n v_sub_f32 %4, |%4|, %6"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "s"(s0), "s"(s1));)
         } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
             REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
         }
@@ -121,6 +147,10 @@ int main() {
     run<9>("32 v_pk_add_f32 sgpr src", 32, 0);
     run<8>("32 v_max3_f32", 32, 0);
     run<10>("walk box test (26 VALU)", 26, 0);
+    run<11>("box test, clamp (20 VALU)", 20, 0);
+    run<12>("32 v_pk_*_f16", 32, 0);
+    run<13>("32 v_pk_*_f16 sgpr src", 32, 0);
+    run<14>("32 v_sub |a|, sgpr (VOP3)", 32, 0);
     run<2>("32 VALU + 32 SALU", 32, 32);
     run<3>("32 VALU + 16 SALU", 32, 16);
     return 0;
