@@ -53,6 +53,7 @@ def parse():
                     help="diagnostic (1 GPU): render only rank 0's tile share of an N-rank frame, no gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the N-rank path)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for every rank (rehearsal: N ranks on one GPU); default LOCAL_RANK")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: assemble with torch.distributed all-gather instead of the library's communicator")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
     ap.add_argument("--knn-points", type=int, default=10_000_000)
@@ -216,20 +217,20 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
         threads = max(1, min(O.hardware_threads(), len(os.sched_getaffinity(0))))
 
         def cpu_knn(nthreads, budget_s):
-            m = 2000
+            m = 500
             t0 = time.perf_counter()
-            O.knn(buf, pts_all[:m], k, threads=nthreads)
+            O.knn(buf, pts_all[:m], k, threads=nthreads, tuned=True)
             tp = time.perf_counter() - t0
             m = int(min(n_total, max(m, m / max(tp, 1e-6) * budget_s)))
             t0 = time.perf_counter()
-            O.knn(buf, pts_all[:m], k, threads=nthreads)
+            O.knn(buf, pts_all[:m], k, threads=nthreads, tuned=True)
             tc = time.perf_counter() - t0
             return m, tc
 
         m1, t1c = cpu_knn(1, 3.0)
         mN, tNc = cpu_knn(threads, 4.0)
         out["cpu_baseline"] = {"value": mN / tNc, "unit": "queries/s", "cores": threads, "kind": "port",
-                               "sample": f"k=8, {mN} of the same points, oracle_knn (C++ restatement, best-so-far pruning), "
+                               "sample": f"k=8, {mN} of the same points, oracle_knn_tuned (C++ restatement, pruned against the k-th best), "
                                          f"{threads} threads, {tNc:.2f} s",
                                "one_thread_value": m1 / t1c,
                                "one_thread_sample": f"k=8, {m1} of the same points, 1 thread, {t1c:.2f} s"}
@@ -450,8 +451,31 @@ def main():
                 sl.part_ptrs.append((P.rank_tiles(r, world, tiles), tuple(t.data_ptr() for t in part)))
             sl.out_ptrs = (sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(), sl.o_prim.data_ptr())
 
+        # Assembly through the library's own communicator (sdfgpu_render_frame_comm: tile share ->
+        # grouped ncclSend / ncclRecv to rank 0 -> untile), the path a host without torch uses.  If
+        # the communicator cannot be made, the torch.distributed all-gather path below does the same job.
+        comm = None
+        if a.backend == "nccl" and not a.torch_gather:
+            try:
+                box = [S.SdfComm.make_id(gpu) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = S.SdfComm(gpu, box[0], rank, world)
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench rank {rank}] library communicator unavailable ({e}); using torch all-gather", file=sys.stderr)
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+        gather_kind = "RCCL grouped send/recv to rank 0 (sdfgpu_render_frame_comm)" if comm is not None else (f"{a.backend} all-gather (torch.distributed)")
+
         def step(k=0):
             sl = slots[k % depth]
+            if comm is not None:
+                ptrs = sl.out_ptrs if rank == 0 else (0, 0, 0, 0)
+                comm.render_frame(cam, w, h, mp, 0, *ptrs, sl.stream.cuda_stream)
+                return
             with torch.cuda.stream(sl.stream):
                 gpu.render_tiles_dev(cam, w, h, mp, first, stride, cnt, *sl.mine_ptrs, sl.stream.cuda_stream)
                 if a.backend == "nccl":
@@ -545,7 +569,7 @@ def main():
                 "frames_in_flight": depth,
                 "tile_order": not a.no_tile_order,
                 "camera": "static (every frame the same view; the longest-first tile order is learned from the previous frame)",
-                "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL all-gather",
+                "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + {gather_kind}",
                 "hit_fraction": hit_frac,
                 "assembly_check": assembly_check,
             },

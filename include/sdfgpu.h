@@ -44,7 +44,8 @@ typedef enum sdfgpu_status {
     SDFGPU_ERR_TOO_DEEP = -7,        /* level >= 255 (faux_shader.rs:100 stack of 256) */
     SDFGPU_ERR_NON_FINITE = -8,      /* NaN/Inf in a matrix the path evaluates (SURVEY C-10) */
     SDFGPU_ERR_POINT_W = -9,         /* a host query point has w != 1 */
-    SDFGPU_ERR_TOO_LARGE = -10       /* k > SDFGPU_MAX_K, image too large, ... */
+    SDFGPU_ERR_TOO_LARGE = -10,      /* k > SDFGPU_MAX_K, image too large, ... */
+    SDFGPU_ERR_COMM = -11            /* RCCL missing or a collective call failed (message has the detail) */
 } sdfgpu_status;
 
 /* Record layouts a producer may have (SURVEY 8b "layout caveat"). */
@@ -254,6 +255,29 @@ int sdfgpu_untile_dev(sdfgpu_ctx* ctx, uint32_t width, uint32_t height,
                       const float* d_normal_t, const uint32_t* d_prim_t,
                       uint8_t* d_hit, float* d_depth, float* d_normal_xyz,
                       uint32_t* d_prim, void* hip_stream);
+
+/* ---- multi-GPU framebuffer assembly ------------------------------------- */
+/* No reference counterpart (the crate is single-threaded).  One process per GPU, each with
+ * its own context and the same tree uploaded.  A communicator wraps an RCCL communicator (bound at
+ * run time from librccl.so.1): one rank calls sdfgpu_comm_get_id and ships the SDFGPU_COMM_ID_BYTES
+ * opaque bytes to the others by any means it has (MPI, a file, torch.distributed), then every rank
+ * calls sdfgpu_comm_create -- collectively, as ncclCommInitRank requires. */
+#define SDFGPU_COMM_ID_BYTES 128
+typedef struct sdfgpu_comm sdfgpu_comm;
+int sdfgpu_comm_get_id(sdfgpu_ctx* ctx, void* id_out);
+int sdfgpu_comm_create(sdfgpu_ctx* ctx, const void* id, int rank, int world, sdfgpu_comm** out);
+void sdfgpu_comm_destroy(sdfgpu_comm* comm);
+/* One frame across the communicator.  Every rank calls it with the same camera, size and march
+ * parameters; rank r renders tiles r, r + world, ... (sdfgpu_render_tiles_dev) into a packed buffer
+ * the communicator owns; the buffers travel to `root` in ONE grouped ncclSend / ncclRecv (a
+ * point-to-point transfer per peer: over xGMI each on its own link); `root` scatters them into its
+ * row-major planes (as sdfgpu_render_dev writes them).  On the other ranks the output pointers are
+ * not touched and may be NULL.  Asynchronous on hip_stream; frames on different streams of one
+ * communicator may be in flight together (at most 8 streams keep their staging). */
+int sdfgpu_render_frame_comm(sdfgpu_ctx* ctx, sdfgpu_comm* comm, const sdfgpu_camera* cam,
+                             uint32_t width, uint32_t height, const sdfgpu_march_params* mp, int root,
+                             uint8_t* d_hit, float* d_depth, float* d_normal_xyz, uint32_t* d_prim,
+                             void* hip_stream);
 
 /* ---- instrumentation ---------------------------------------------------- */
 /* Run the counting variant of the same kernels (slower) and return the work

@@ -454,6 +454,63 @@ int oracle_knn(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, u
     });
 }
 
+// The same k nearest with real pruning (the CPU baseline of the kNN leg: the exhaustive form above is
+// O(N) per query and would be a strawman): the walk of `Tuned`, pruning against the k-th best so far.
+struct TunedK {
+    const Tree& t;
+    float margin;
+    uint32_t k;
+    std::vector<DI> best;   // ascending under better(), at most k entries
+    float radius() const { return best.size() < k ? INF : best.back().d; }
+    void offer(DI c) {
+        if (best.size() == k && !better(c, best.back())) return;
+        auto it = std::upper_bound(best.begin(), best.end(), c, better);
+        best.insert(it, c);
+        if (best.size() > k) best.pop_back();
+    }
+    void visit(uint32_t i, V4 p) {
+        const SdfOperationBlock& b = t.dt[i];
+        if (t.dead[i]) return;
+        if (b.is_primitive) {
+            float d;
+            if (prim_dispatch(b.op_code, b.op_specific, mat_mul(b.bounding_box.trans_inverse, p), &d)) offer(DI{d, t.prim_id[i]});
+            return;
+        }
+        V4 pc = mat_mul(b.bounding_box.trans_inverse, p);
+        uint32_t l = i + 1, end = i + 1 + b.len, r = l + 1 + t.dt[l].len;
+        if (r >= end) { visit(l, pc); return; }
+        float ml = mindist(t.dt[l].bounding_box, pc), mr = mindist(t.dt[r].bounding_box, pc);
+        uint32_t a = l, c = r;
+        float ma = ml, mc = mr;
+        if (mr < ml) { a = r; c = l; ma = mr; mc = ml; }
+        if (!(ma > radius() + margin)) visit(a, pc);
+        if (!(mc > radius() + margin)) visit(c, pc);
+    }
+};
+
+int oracle_knn_tuned(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
+                     const float* pts_xyzw, size_t npts, uint32_t k, int threads, float* out_dist,
+                     uint32_t* out_prim) {
+    Tree t;
+    int rc = build_tree(t, dt, ut, n);
+    if (rc) return rc;
+    return parallel_for(npts, threads, [&](size_t a, size_t b) -> int {
+        TunedK q{t, 0.f, k, {}};
+        q.best.reserve(k + 1);
+        for (size_t i = a; i < b; ++i) {
+            V4 p{pts_xyzw[4 * i], pts_xyzw[4 * i + 1], pts_xyzw[4 * i + 2], pts_xyzw[4 * i + 3]};
+            q.best.clear();
+            q.margin = 1e-4f * (1.0f + std::fabs(p.x) + std::fabs(p.y) + std::fabs(p.z));
+            if (t.n && k) q.visit(0, p);
+            for (uint32_t j = 0; j < k; ++j) {
+                out_dist[i * k + j] = j < q.best.size() ? q.best[j].d : INF;
+                out_prim[i * k + j] = j < q.best.size() ? q.best[j].id : SDF_NO_PRIM;
+            }
+        }
+        return 0;
+    });
+}
+
 // Value of one primitive's SDF at points (used by normal tests).
 int oracle_eval_prim(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
                      uint32_t prim, const float* pts_xyzw, size_t npts, float* out) {

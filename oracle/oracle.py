@@ -22,7 +22,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} missing: run `make -C oracle`")
         _lib = C.CDLL(LIB_PATH)
-        for name in ("oracle_nearest", "oracle_knn", "oracle_eval_prim", "oracle_bounds", "oracle_render",
+        for name in ("oracle_nearest", "oracle_knn", "oracle_knn_tuned", "oracle_eval_prim", "oracle_bounds", "oracle_render",
                      "oracle_hardware_threads"):
             getattr(_lib, name).restype = C.c_int
     return _lib
@@ -50,12 +50,15 @@ def nearest(buf, pts_xyzw, mode=MODE_FAUX, threads=1):
     return dist, prim
 
 
-def knn(buf, pts_xyzw, k, threads=1):
+def knn(buf, pts_xyzw, k, threads=1, tuned=False):
+    """k nearest: exhaustive top-k (the contract), or tuned=True the pruned walk (same results on
+    consistent buffers; the CPU baseline of the kNN leg)."""
     p = _pts(pts_xyzw)
     n = p.shape[0]
     dist = np.empty((n, k), np.float32)
     prim = np.empty((n, k), np.uint32)
-    rc = lib().oracle_knn(*_tree_args(buf), C.c_void_p(p.ctypes.data), C.c_size_t(n), C.c_uint32(k),
+    fn = lib().oracle_knn_tuned if tuned else lib().oracle_knn
+    rc = fn(*_tree_args(buf), C.c_void_p(p.ctypes.data), C.c_size_t(n), C.c_uint32(k),
                           C.c_int(threads), C.c_void_p(dist.ctypes.data), C.c_void_p(prim.ctypes.data))
     if rc:
         raise RuntimeError(f"oracle_knn failed: {rc}")

@@ -8,7 +8,7 @@ loudly if it has not been built.
 from . import _ffi
 from ._ffi import (BOUNDS_AABB, BOUNDS_AUTO, BOUNDS_BVH, BOUNDS_NONE, BOUNDS_OBB, NO_PRIM,
                    Camera, MarchParams, load_library)
-from .gpu import SdfGpu, SdfGpuError, camera_look_at, compact_host, march_params
+from .gpu import SdfComm, SdfGpu, SdfGpuError, camera_look_at, compact_host, march_params
 from .scene import (ExpandedSdfNode, Quat, SdfBox, SdfBuilder, SdfCaaClone, SdfError, SdfNode,
                     SdfSphere, SdfTreeBuffer, SdfUnion, Transform, default_extent,
                     random_scene, random_scene_buffer)

@@ -53,7 +53,8 @@ LAYOUT_GLAM_SSE2 = 0
 
 OK = 0
 ERR_INVALID_ARG, ERR_HIP, ERR_NO_TREE, ERR_LAYOUT, ERR_BAD_TREE = -1, -2, -3, -4, -5
-ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE = -6, -7, -8, -9, -10
+ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE, ERR_COMM = -6, -7, -8, -9, -10, -11
+COMM_ID_BYTES = 128
 MAX_K = 16
 STATIC_MAX_POINTS = 262144
 OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER = 0, 1, 2, 3
@@ -152,6 +153,10 @@ GPU_SYMBOLS = {
         [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
     ),
     "sdfgpu_untile_dev": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdfgpu_comm_get_id": (_i, [_vp, _vp]),
+    "sdfgpu_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "sdfgpu_comm_destroy": (None, [_vp]),
+    "sdfgpu_render_frame_comm": (_i, [_vp, _vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _i, _vp, _vp, _vp, _vp, _vp]),
     "sdfgpu_render_stats": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), C.POINTER(Stats)]),
     "sdfgpu_nearest_stats_dev": (_i, [_vp, _vp, _sz, C.POINTER(Stats)]),
     "sdfgpu_knn_stats_dev": (_i, [_vp, _vp, _sz, _u32, C.POINTER(Stats)]),

@@ -272,6 +272,11 @@ int upload_vec(sdfgpu_ctx* c, const std::vector<T>& v, T** dst) {
 
 }  // namespace
 
+namespace sdfgpu {
+int ctx_device(const sdfgpu_ctx* c) { return c->device; }
+int ctx_set_error(sdfgpu_ctx* c, int code, const char* msg) { return set_err(c, code, msg ? msg : ""); }
+}  // namespace sdfgpu
+
 extern "C" {
 
 const char* sdfgpu_status_string(int s) {
@@ -287,6 +292,7 @@ const char* sdfgpu_status_string(int s) {
         case SDFGPU_ERR_NON_FINITE: return "non-finite value in tree";
         case SDFGPU_ERR_POINT_W: return "query point with w != 1";
         case SDFGPU_ERR_TOO_LARGE: return "size limit exceeded";
+        case SDFGPU_ERR_COMM: return "RCCL communicator error";
     }
     return "unknown status";
 }

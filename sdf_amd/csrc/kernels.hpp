@@ -25,6 +25,10 @@ struct DeviceTree {
     float box_scale = 1.f;
 };
 
+// Internal accessors of the opaque context for comm.cpp (defined in api.cpp).
+int ctx_device(const sdfgpu_ctx* c);
+int ctx_set_error(sdfgpu_ctx* c, int code, const char* msg);
+
 // st != nullptr selects the counting instantiation of the same kernel.
 hipError_t launch_nearest(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n,
                           float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s);

@@ -193,3 +193,33 @@ class SdfGpu:
         st = _ffi.Stats()
         self._check(self._lib.sdfgpu_render_stats(self._h, C.byref(cam), width, height, C.byref(mp), C.byref(st)))
         return st.as_dict()
+
+
+class SdfComm:
+    """sdfgpu_comm: an RCCL communicator of the library (one rank per process / GPU) for framebuffer
+    assembly.  `id_bytes` comes from SdfComm.make_id(gpu) on one rank and is shipped to the others."""
+
+    @staticmethod
+    def make_id(gpu):
+        buf = C.create_string_buffer(_ffi.COMM_ID_BYTES)
+        gpu._check(gpu._lib.sdfgpu_comm_get_id(gpu._h, buf))
+        return buf.raw
+
+    def __init__(self, gpu, id_bytes, rank, world):
+        self._gpu = gpu
+        h = C.c_void_p()
+        gpu._check(gpu._lib.sdfgpu_comm_create(gpu._h, id_bytes, rank, world, C.byref(h)))
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def render_frame(self, cam, width, height, mp, root, d_hit, d_depth, d_normal, d_prim, stream=0):
+        g = self._gpu
+        g._check(g._lib.sdfgpu_render_frame_comm(g._h, self._h, C.byref(cam), width, height, C.byref(mp), root,
+                                                 d_hit, d_depth, d_normal, d_prim, stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._gpu._lib.sdfgpu_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close

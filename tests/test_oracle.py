@@ -192,3 +192,14 @@ def test_render_modes_agree_and_normals_are_unit():
     # strided sampling renders the same pixels
     s = O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, pix_first=3, pix_stride=7, pix_count=50)
     assert np.array_equal(s["depth"].view(np.uint32), a["depth"][3:3 + 7 * 50:7].view(np.uint32))
+
+
+def test_tuned_knn_equals_exhaustive_knn():
+    # the pruned k-nearest walk (the kNN leg's CPU baseline) returns what the exhaustive top-k returns
+    for n, seed in ((1, 5), (5, 6), (300, 7)):
+        buf = S.random_scene_buffer(n, seed)
+        pts = make_points(500, S.default_extent(n), seed)
+        for k in (1, 3, 8):
+            d0, i0 = O.knn(buf, pts, k)
+            d1, i1 = O.knn(buf, pts, k, tuned=True, threads=2)
+            assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(i0, i1)
