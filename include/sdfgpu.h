@@ -198,7 +198,12 @@ typedef enum sdfgpu_option {
      * few tiles that run all max_steps then overlap the bulk of the frame instead of
      * trailing it).  Frames of at least 1024 tiles, single-pass march only.  0: tiles in
      * raster order. */
-    SDFGPU_OPT_TILE_ORDER = 3
+    SDFGPU_OPT_TILE_ORDER = 3,
+    /* instrumentation: 1: sdfgpu_nearest_stats_dev counts with the hand-scheduled walk's own visit
+     * counters (queries, wave_inner, wave_leaf only) instead of the C++ state machine that fills
+     * every counter; 0 (default).  The two must report the same visits: the production kernels run
+     * the former, the roofline units come from the latter. */
+    SDFGPU_OPT_STATS_ASM_WALK = 4
 } sdfgpu_option;
 int sdfgpu_set_option(sdfgpu_ctx* ctx, int option, double value);
 

@@ -51,6 +51,7 @@ struct sdfgpu_ctx {
     bool compaction = false;
     std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
     bool reorder = true;
+    bool stats_asm_walk = false;    // SDFGPU_OPT_STATS_ASM_WALK
     float skip_ext_opt = 0.f;    // SDFGPU_OPT_SKIP_EXTENSION as set (< 0: half the mean primitive size)
     float mean_extent = 0.f;
     // sdfgpu_nearest_dev_static: address of sort.hip's file-scope scratch array on this device
@@ -458,7 +459,7 @@ int sdfgpu_nearest_stats_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, sdfgpu
     const uint32_t* order = nullptr;
     if ((rc = make_order(c, d_pts, n, c->stream, &order))) return rc;
     HIP_TRY(c, launch_nearest(c->tree, d_pts, order, (uint32_t)n, (float*)c->out_a.p, (uint32_t*)c->out_b.p,
-                              (sdfgpu_stats*)c->stats.p, c->stream));
+                              (sdfgpu_stats*)c->stats.p, c->stream, c->stats_asm_walk));
     HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SDFGPU_OK;
@@ -498,6 +499,9 @@ int sdfgpu_set_option(sdfgpu_ctx* c, int option, double value) {
             return SDFGPU_OK;
         case SDFGPU_OPT_COMPACTION:
             c->compaction = value != 0.0;
+            return SDFGPU_OK;
+        case SDFGPU_OPT_STATS_ASM_WALK:
+            c->stats_asm_walk = value != 0.0;
             return SDFGPU_OK;
         case SDFGPU_OPT_TILE_ORDER:
             c->tile_order = value != 0.0;

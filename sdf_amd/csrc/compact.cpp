@@ -437,7 +437,6 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 return fail(err, SDFGPU_ERR_BAD_TREE, "uptree block %u does not match downtree node %u", j, post[j]);
         }
     }
-    if (max_level_live > 64) return fail(err, SDFGPU_ERR_TOO_DEEP, "tree depth %u exceeds the 64-entry wave stack", max_level_live);
 
     if (!identity_inner || !exact_rows) {
         // General path: no pruning, the literal per-level point chain.
@@ -477,6 +476,11 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
 
     uint32_t mode = bounds;
     if (mode == SDFGPU_BOUNDS_AUTO) mode = rigid ? SDFGPU_BOUNDS_BVH : SDFGPU_BOUNDS_NONE;
+    // The per-wavefront stack holds 64 pending subtrees.  Only the modes that walk the BUFFER's topology
+    // depend on its depth; BVH mode rebuilds the hierarchy under its own depth budget, so any buffer the
+    // reference's 256-frame stack accepts (levels < 255, checked above) is accepted there.
+    if (mode != SDFGPU_BOUNDS_BVH && max_level_live > 64)
+        return fail(err, SDFGPU_ERR_TOO_DEEP, "tree depth %u exceeds the 64-entry wave stack (use AUTO / BVH bounds)", max_level_live);
     if ((mode == SDFGPU_BOUNDS_AABB || mode == SDFGPU_BOUNDS_BVH || mode == SDFGPU_BOUNDS_OBB) && !rigid)
         return fail(err, SDFGPU_ERR_BAD_TREE,
                     "pruned bounds (AABB, BVH, OBB) need rigid leaf transforms (trans_inverse is not orthonormal); use AUTO or NONE");

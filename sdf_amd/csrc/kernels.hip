@@ -362,7 +362,7 @@ pop:
 // two wait states for that); lane masks go VALU->SALU->VALU, which interlocks.
 constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 
-#define SDFGPU_WALK_ASM(LBMIN_K0, LBMIN_K1, LBMIN_A, PREFETCH)                                                   \
+#define SDFGPU_WALK_ASM(LBMIN_K0, LBMIN_K1, LBMIN_A, PREFETCH, CNT_INNER, CNT_LEAF)                                                   \
     "s_cmp_eq_u32 %[cur], -2\n\t"                                                                      \
     "s_cbranch_scc1 .Lpop%=\n"                                                                         \
     ".Ltop%=:\n\t"                                                                                     \
@@ -371,6 +371,7 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_lshl_b32 %[t0], %[cur], 6\n\t"                                                                  \
     "s_load_dwordx16 s[80:95], %[base], %[t0]\n\t"                                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
+    CNT_INNER                                                                                          \
     PREFETCH                                                                                           \
     "v_subrev_f32 %[a], s80, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s81, %[py]\n\t"                                                              \
@@ -447,6 +448,7 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_mov_b32 %[cur], -1\n\t"                                                                         \
     "s_branch .Lexit%=\n"                                                                              \
     ".Ldone%=:\n\t"                        /* leaf reference: fetch its record (bit 31 shifts out) */    \
+    CNT_LEAF                                                                                           \
     "s_lshl_b32 %[t0], %[cur], 6\n\t"                                                                  \
     "s_load_dwordx16 %[rec], %[lbase], %[t0]\n"                                                        \
     ".Lexit%=:\n\t"                        /* nothing (prefetches included) may still be in flight */   \
@@ -471,36 +473,50 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_load_dword s97, %[mk0], %[t1]\n\t"
 #endif
 
-template <bool TRACK>
+// DBG: the block also counts the internal nodes and leaves it visits in two SGPRs (the instrumented
+// build behind SDFGPU_OPT_STATS_ASM_WALK; tests compare them with the C++ walk's counters).
+template <bool TRACK, bool DBG>
 __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& refs, float& lb, float thr, float px,
                                              float py, float pz, unsigned long long drive, const GpuInner* base,
-                                             const GpuLeaf* lbase, uint32_t sa, f32x16& rec) {
+                                             const GpuLeaf* lbase, uint32_t sa, f32x16& rec, uint32_t& n_inner,
+                                             uint32_t& n_leaf) {
     unsigned long long m0, m1, t;
     uint32_t t0, t1;
     float a, b, c, d, k0, k1;
-#define SDFGPU_WALK_OPERANDS                                                                                          \
-    : [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [mk0] "=&s"(m0), [mk1] "=&s"(m1), [t] "=&s"(t), \
+#define SDFGPU_WALK_OUT                                                                                               \
+    [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [mk0] "=&s"(m0), [mk1] "=&s"(m1), [t] "=&s"(t), \
       [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [k0] "=&v"(k0),          \
-      [k1] "=&v"(k1), [rec] "=&s"(rec)                                                                                \
-    : [thr] "v"(thr), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [drive] "s"(drive), [base] "s"(base), [lbase] "s"(lbase), [sa] "v"(sa)      \
-    : "vcc", "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",       \
+      [k1] "=&v"(k1), [rec] "=&s"(rec)
+#define SDFGPU_WALK_IN                                                                                                \
+    [thr] "v"(thr), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [drive] "s"(drive), [base] "s"(base), [lbase] "s"(lbase), [sa] "v"(sa)
+#define SDFGPU_WALK_CLOBBER                                                                                           \
+    "vcc", "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",       \
       "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define SDFGPU_LB_K0 "v_min_f32 %[lb], %[lb], %[k0]\n\t"
+#define SDFGPU_LB_K1 "v_min_f32 %[lb], %[lb], %[k1]\n\t"
+#define SDFGPU_LB_A "v_min_f32 %[lb], %[lb], %[a]\n\t"
     // The block writes M0 (lane select of v_writelane).  M0 is a reserved register to this compiler: it
     // never keeps a value live in it across other code and re-materialises it before each use of its own,
     // so it cannot be listed as a clobber (-Winline-asm: "clobber list contains reserved registers: m0").
-    if constexpr (TRACK) {
-        asm volatile(SDFGPU_WALK_ASM("v_min_f32 %[lb], %[lb], %[k0]\n\t", "v_min_f32 %[lb], %[lb], %[k1]\n\t",
-                                     "v_min_f32 %[lb], %[lb], %[a]\n\t", SDFGPU_WALK_PREFETCH) SDFGPU_WALK_OPERANDS);
+    if constexpr (DBG) {
+        static_assert(!TRACK, "the counting walk is instantiated for the query kernels only");
+        asm volatile(SDFGPU_WALK_ASM("", "", "", SDFGPU_WALK_PREFETCH, "s_add_u32 %[ni], %[ni], 1\n\t", "s_add_u32 %[nl], %[nl], 1\n\t")
+                     : SDFGPU_WALK_OUT, [ni] "+s"(n_inner), [nl] "+s"(n_leaf) : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);
+    } else if constexpr (TRACK) {
+        asm volatile(SDFGPU_WALK_ASM(SDFGPU_LB_K0, SDFGPU_LB_K1, SDFGPU_LB_A, SDFGPU_WALK_PREFETCH, "", "")
+                     : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);
     } else {
-        asm volatile(SDFGPU_WALK_ASM("", "", "", SDFGPU_WALK_PREFETCH) SDFGPU_WALK_OPERANDS);
+        asm volatile(SDFGPU_WALK_ASM("", "", "", SDFGPU_WALK_PREFETCH, "", "") : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);
     }
-#undef SDFGPU_WALK_OPERANDS
+#undef SDFGPU_WALK_OUT
+#undef SDFGPU_WALK_IN
+#undef SDFGPU_WALK_CLOBBER
 }
 
-template <int MODE, class Acc>
+template <int MODE, bool DBG, class Acc>
 __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, float py, float pz,
                                                 unsigned long long drive, float ext, Acc& acc,
-                                                float* __restrict__ stk, uint32_t lane) {
+                                                float* __restrict__ stk, uint32_t lane, WaveCounters& wc) {
     uint32_t cur = __builtin_amdgcn_readfirstlane(T.root);
     if (cur == REF_NONE) return;
     const float mg = prune_margin<MODE>(T, px, py, pz);
@@ -512,9 +528,10 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
     // LDS byte address of this lane's slot in stack level 0; level l is 256 bytes further
     const uint32_t sa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)stk + lane * 4u;
     const float sx = px * T.bscale, sy = py * T.bscale, sz = pz * T.bscale;   // the boxes' coordinates
+    uint32_t n_inner = 0, n_leaf = 0;   // DBG only
     for (;;) {
         f32x16 L;   // the leaf's record, fetched inside the block (undefined when the walk is over)
-        walk_advance<Acc::TRACKS>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L);
+        walk_advance<Acc::TRACKS, DBG>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L, n_inner, n_leaf);
         cur = __builtin_amdgcn_readfirstlane(cur);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (cur == REF_NONE) break;
@@ -524,14 +541,21 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
         cur = REF_POP;
     }
     if constexpr (Acc::TRACKS) acc.lb_key = lb;
+    if constexpr (DBG) {
+        wc.wave_inner += __builtin_amdgcn_readfirstlane(n_inner);
+        wc.wave_leaf += __builtin_amdgcn_readfirstlane(n_leaf);
+        wc.lane_queries += ((drive >> lane) & 1ull) ? 1u : 0u;
+    }
 }
 
-template <int MODE, bool COUNT, class Acc>
+// COUNT: 0 = production, 1 = the C++ state machine with every counter, 2 = the assembly walk with its
+// wave-level visit counters (query kernels only; what SDFGPU_OPT_STATS_ASM_WALK selects).
+template <int MODE, int COUNT, class Acc>
 __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, unsigned long long drive,
                                             float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
                                             WaveCounters& wc) {
-    if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT) nn_traverse_cxx<MODE, COUNT>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else nn_traverse_asm<MODE>(T, px, py, pz, drive, ext, acc, stk, lane);
+    if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT == 1) nn_traverse_cxx<MODE, COUNT != 0>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else nn_traverse_asm<MODE, COUNT == 2>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
 }
 
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
@@ -564,7 +588,7 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
 // the primitive index.  One point per lane.  `order` (optional) is a
 // permutation that makes consecutive lanes spatially close (Morton order);
 // results are written at the original index.
-template <int MODE, bool COUNT>
+template <int MODE, int COUNT>
 __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* __restrict__ pts,
                                                       const uint32_t* __restrict__ order, uint32_t n,
                                                       float* __restrict__ out_dist, uint32_t* __restrict__ out_prim,
@@ -1185,7 +1209,7 @@ static TreeView make_view(const DeviceTree& d) {
     return v;
 }
 
-template <bool COUNT>
+template <int COUNT>
 static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n,
                                    float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -1210,15 +1234,16 @@ hipError_t launch_box_bounds(const SdfBoundingBoxBlock* d_box, const float* d_pt
 }
 
 hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, float* out_dist,
-                          uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
+                          uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s, bool stats_asm_walk) {
     if (d.gen) {   // general path: exhaustive literal chain (no counters, no reordering needed)
         if (n == 0) return hipSuccess;
         query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, (const float4*)pts, n, 1,
                                                                                        out_dist, out_prim);
         return hipGetLastError();
     }
-    return st ? launch_nearest_t<true>(d, pts, order, n, out_dist, out_prim, st, s)
-              : launch_nearest_t<false>(d, pts, order, n, out_dist, out_prim, nullptr, s);
+    if (st) return stats_asm_walk ? launch_nearest_t<2>(d, pts, order, n, out_dist, out_prim, st, s)
+                                  : launch_nearest_t<1>(d, pts, order, n, out_dist, out_prim, st, s);
+    return launch_nearest_t<0>(d, pts, order, n, out_dist, out_prim, nullptr, s);
 }
 
 

@@ -30,8 +30,9 @@ int ctx_device(const sdfgpu_ctx* c);
 int ctx_set_error(sdfgpu_ctx* c, int code, const char* msg);
 
 // st != nullptr selects the counting instantiation of the same kernel.
+// stats_asm_walk (with st): count with the assembly walk's own wave-level counters instead of the C++ walk.
 hipError_t launch_nearest(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n,
-                          float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s);
+                          float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s, bool stats_asm_walk = false);
 
 // k nearest (k <= SDFGPU_MAX_K): out[i*k + j], ascending by (distance, larger index first).
 hipError_t launch_knn(const DeviceTree& d, const float* pts_xyzw, const uint32_t* order, uint32_t n, uint32_t k,

@@ -137,3 +137,24 @@ def test_obb_mode_requires_affine_boxes():
     buf = mutate(good(), lambda d, u: d["bounding_box"]["scale"][1].__setitem__(3, 1.0))
     assert S.compact_host(buf, bounds=S.BOUNDS_AABB)[0] == 0
     assert S.compact_host(buf, bounds=S.BOUNDS_OBB)[0] == _ffi.ERR_BAD_TREE
+
+
+def deep_chain(depth):
+    """union(p0, union(p1, union(p2, ...))): a buffer `depth` levels deep, as the crate's builder nests it."""
+    node = S.SdfBuilder.primitive(S.SdfSphere(0.5)).transform(S.Transform.from_xyz(3.0 * depth, 0, 0))
+    for k in range(depth - 1, -1, -1):
+        leaf = S.SdfBuilder.primitive(S.SdfBox((0.4, 0.6, 0.5))).transform(S.Transform.from_xyz(3.0 * k, 0.5 * (k % 3), 0))
+        node = leaf.operation(S.SdfUnion(0.0)).with_(node)
+    return node.finalize().expanded().make_buffer()
+
+
+def test_deep_buffer_is_accepted_when_the_library_builds_the_hierarchy():
+    # the reference's stack holds 256 frames (faux_shader.rs:100); only modes that walk the buffer's own
+    # topology are limited by the 64-entry wave stack
+    buf = deep_chain(100)
+    assert int(buf.downtree_buffer["level"].max()) > 64
+    rc, info, msg = S.compact_host(buf)
+    assert rc == 0 and info.bounds == S.BOUNDS_BVH and info.stack_depth <= 64, msg
+    for mode in (S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE):
+        rc, _, msg = S.compact_host(buf, bounds=mode)
+        assert rc == _ffi.ERR_TOO_DEEP, msg

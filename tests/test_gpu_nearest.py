@@ -136,3 +136,36 @@ def test_dense_nn_single_and_chain_on_the_gpu(gpu, chain):
                 assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
                 gt = np.array([prim.distance_to((inv @ q.astype(np.float64))[:3]) for q in pts])
                 assert np.all(np.abs(d - gt) <= 4e-5 * np.maximum(1.0, np.abs(gt)))
+
+
+def test_buffer_deeper_than_the_wave_stack(gpu):
+    # 100 nested unions: deeper than the 64-entry wave stack, fine for the reference's 256 frames
+    from test_compact_validation import deep_chain
+    buf = deep_chain(100)
+    pts = make_points(4096, 150.0, seed=9)
+    pts[:, 0] = np.abs(pts[:, 0]) * 1.7
+    _check(gpu, buf, pts, S.BOUNDS_AUTO)
+
+
+@pytest.mark.parametrize("n,reorder", [(300, True), (5000, True), (5000, False)])
+def test_assembly_walk_visits_what_the_cxx_walk_visits(gpu, n, reorder):
+    # the production kernels run the hand-scheduled walk, the roofline units are counted by the C++
+    # state machine: both must visit the same internal nodes and leaves, wavefront by wavefront
+    import torch
+    from sdf_amd import _ffi
+
+    buf = S.random_scene_buffer(n, 0xA5A5 + n)
+    gpu.upload_tree(buf)
+    gpu.set_reorder(reorder)
+    pts = torch.from_numpy(make_points(50_000, S.default_extent(n), seed=n)).cuda()
+    try:
+        gpu.set_option(_ffi.OPT_STATS_ASM_WALK, 0)
+        a = gpu.nearest_stats_dev(pts.data_ptr(), pts.shape[0])
+        gpu.set_option(_ffi.OPT_STATS_ASM_WALK, 1)
+        b = gpu.nearest_stats_dev(pts.data_ptr(), pts.shape[0])
+    finally:
+        gpu.set_option(_ffi.OPT_STATS_ASM_WALK, 0)
+        gpu.set_reorder(True)
+    assert a["wave_inner"] > 0 and a["wave_leaf"] > 0
+    for key in ("queries", "wave_inner", "wave_leaf"):
+        assert a[key] == b[key], (key, a[key], b[key])
