@@ -43,10 +43,12 @@ struct sdfgpu_ctx {
         DevBuf order;               // [cost | iota | sorted keys | order] x tiles, then the sort's temp storage
         uint32_t order_tiles = 0;   // tile count the buffers are laid out for
         size_t order_temp = 0;      // bytes of sort temp storage behind the four arrays
-        uint64_t order_sig = 0;     // frame geometry the recorded costs belong to
+        uint32_t order_geom[6] = {0, 0, 0, 0, 0, 0};   // frame geometry the recorded costs belong to
         bool order_valid = false;
+        uint64_t stamp = 0;         // last use (least recently used entry is recycled)
     };
     std::vector<MarchScratch> march;
+    uint64_t march_clock = 0;
     bool tile_order = true;         // SDFGPU_OPT_TILE_ORDER
     bool compaction = false;
     std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
@@ -176,14 +178,32 @@ std::vector<uint32_t> default_pass_steps() {
     return {40};   // two passes; best of the schedules measured on the bench frame
 }
 
-// Per-stream scratch of a context (at most 16 streams; nullptr beyond that).
+// Per-stream scratch of a context.  At most 16 streams keep theirs; beyond that the least recently
+// used entry is recycled (its stream is synchronised first, its device memory freed), so a caller that
+// creates and destroys streams over time neither leaks nor runs out.
 sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream) {
     for (auto& m : c->march)
-        if (m.stream == stream) return &m;
-    if (c->march.size() >= 16) return nullptr;
-    c->march.emplace_back();
-    c->march.back().stream = stream;
-    return &c->march.back();
+        if (m.stream == stream) {
+            m.stamp = ++c->march_clock;
+            return &m;
+        }
+    if (c->march.size() < 16) {
+        c->march.emplace_back();
+    } else {
+        size_t lru = 0;
+        for (size_t i = 1; i < c->march.size(); ++i)
+            if (c->march[i].stamp < c->march[lru].stamp) lru = i;
+        sdfgpu_ctx::MarchScratch& old = c->march[lru];
+        if (hipStreamSynchronize(old.stream) != hipSuccess) (void)hipDeviceSynchronize();   // the stream may be gone
+        if (old.buf.p) (void)hipFree(old.buf.p);
+        if (old.order.p) (void)hipFree(old.order.p);
+        old = sdfgpu_ctx::MarchScratch();
+        std::swap(old, c->march.back());
+    }
+    sdfgpu_ctx::MarchScratch& m = c->march.back();
+    m.stream = stream;
+    m.stamp = ++c->march_clock;
+    return &m;
 }
 
 int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t max_steps, RenderScratch* rs,
@@ -199,7 +219,6 @@ int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t
     const size_t total = render_scratch_bytes(tile_count, &sb, &cb);
     if (bounds->size() == 2) return SDFGPU_OK;   // single pass: no pass state
     sdfgpu_ctx::MarchScratch* ms = stream_scratch(c, stream);
-    if (!ms) return set_err(c, SDFGPU_ERR_TOO_LARGE, "compaction: more than 16 distinct streams on one context");
     DevBuf* mb = &ms->buf;
     int rc = reserve(c, *mb, total);
     if (rc) return rc;
@@ -246,10 +265,9 @@ int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint3
         order = (uint32_t*)(base + 3 * arr);
         temp = base + 4 * arr;
         temp_bytes = ms->order_temp;
-        const uint64_t sig = ((uint64_t)w << 48) ^ ((uint64_t)h << 32) ^ ((uint64_t)tile_first << 16) ^ ((uint64_t)tile_stride << 8) ^
-                             (uint64_t)tile_count ^ ((uint64_t)mp->max_steps << 40);
-        if (ms->order_sig != sig) ms->order_valid = false;
-        ms->order_sig = sig;
+        const uint32_t geom[6] = {w, h, tile_first, tile_stride, tile_count, mp->max_steps};
+        if (std::memcmp(ms->order_geom, geom, sizeof geom) != 0) ms->order_valid = false;
+        std::memcpy(ms->order_geom, geom, sizeof geom);
         rs.tile_cost = cost;
         rs.tile_order = ms->order_valid ? order : nullptr;
     }

@@ -26,6 +26,13 @@ def test_general_nearest_and_knn(gpu, n):
     d, i = gpu.nearest(pts)
     d0, i0 = O.nearest(buf, pts, O.MODE_EXHAUSTIVE, threads=8)
     assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+    # sdfgpu.h promises "the value the reference returns": on these buffers the as-written walk, whose
+    # union prune (faux_shader.rs:117-126) tests boxes in a frame the re-based point has left, must
+    # agree with the exhaustive one -- an empirical property, so it is checked, not assumed
+    df, fi = O.nearest(buf, pts, O.MODE_FAUX, threads=8)
+    assert np.array_equal(bits(df), bits(d0)) and np.array_equal(fi, i0)
+    ff, _ = O.nearest(buf, pts[:64], O.MODE_FAUX_FAITHFUL)
+    assert np.array_equal(bits(ff), bits(d0[:64]))
     for k in (3, 8):
         kd, ki = gpu.knn(pts[:500], k)
         kd0, ki0 = O.knn(buf, pts[:500], k, threads=8)

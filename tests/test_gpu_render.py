@@ -289,3 +289,28 @@ def test_render_scaled_leaf_counter_example(gpu):
     mp = S.march_params(max_steps=64, eps_hit=1e-3, t_min=0.0, t_max=400.0, normal_h=1e-3)
     gpu.upload_tree(buf)
     _compare(gpu.render(cam, w, h, mp), O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE))
+
+
+def test_more_streams_than_scratch_slots(gpu):
+    # per-stream march scratch is recycled least-recently-used beyond 16 streams (it used to fail with
+    # SDFGPU_ERR_TOO_LARGE once 16 distinct streams had rendered with compaction on)
+    import torch
+
+    n, w, h = 150, 96, 64
+    buf = S.random_scene_buffer(n, 0x57E4)
+    cam, mp = scene_camera(n, w, h)
+    gpu.upload_tree(buf)
+    want = gpu.render(cam, w, h, mp)
+    gpu.set_compaction(True)
+    try:
+        dev = torch.device("cuda:0")
+        for k in range(20):
+            st = torch.cuda.Stream(dev)
+            o = (torch.zeros(w * h, dtype=torch.uint8, device=dev), torch.zeros(w * h, dtype=torch.float32, device=dev),
+                 torch.zeros(w * h * 3, dtype=torch.float32, device=dev), torch.zeros(w * h, dtype=torch.int32, device=dev))
+            gpu.render_dev(cam, w, h, mp, *(t.data_ptr() for t in o), st.cuda_stream)
+            st.synchronize()
+            assert np.array_equal(o[0].cpu().numpy(), want["hit"]), f"stream {k}"
+            assert np.array_equal(bits(o[1].cpu().numpy()), bits(want["depth"])), f"stream {k}"
+    finally:
+        gpu.set_compaction(False)
