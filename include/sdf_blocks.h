@@ -111,6 +111,8 @@ SDF_STATIC_ASSERT(offsetof(SdfOperationUptreeBlock, level) == 208, "ut level off
 enum {
     SDF_PRIM_SPHERE = 0,   /* elements.rs:85-118: floats[0] = radius */
     SDF_PRIM_BOX = 2,      /* build-defined (SURVEY C-7): vec4s[0] = half extents, w = 0 */
+    SDF_PRIM_BOX_FRAME = 5,/* elements.rs:120-152 (private, no distance formula in the crate): vec4s[0] = dimension,
+                              floats[0] = thickness; evaluated only under SDFGPU_EXT_BOX_FRAME */
     SDF_OP_UNION = 0,      /* elements.rs:157-212 */
     SDF_OP_CAA_CLONE = 1   /* elements.rs:215-262; a one-slot clone subtree is +inf in the flat query as written (faux_shader.rs:90) */
 };

@@ -78,6 +78,8 @@ typedef struct sdfgpu_tree_info {
     uint64_t device_bytes;   /* compact tree bytes resident in HBM */
     float scene_lo[3];       /* root AABB (AABB mode) */
     float scene_hi[3];
+    uint32_t extensions;     /* sdfgpu_extension bits that are in effect in this tree (0 = evaluated as the crate is written) */
+    uint32_t reserved;
 } sdfgpu_tree_info;
 
 /* Pinhole camera as plain data.  Ray through pixel (x, y):
@@ -139,6 +141,29 @@ int sdfgpu_sync(sdfgpu_ctx* ctx);
 int sdfgpu_upload_tree(sdfgpu_ctx* ctx, const SdfOperationBlock* dt,
                        const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
                        uint32_t layout, uint32_t bounds);
+/* Opt-in extensions (N-2 of SURVEY 8f).  The crate carries the DATA for all three and evaluates none:
+ * smooth_radius is written into the union's up-block (elements.rs:207-211) and ignored by
+ * uptree_dispatch (faux_shader.rs:87); SdfBoxFrame (op 5, elements.rs:120-152) has no distance formula
+ * and prim_dispatch panics on it (faux_shader.rs:65); a one-slot clone evaluates to +inf because
+ * uptree op 1 returns the branch it never filled (faux_shader.rs:90).  sdfgpu_upload_tree evaluates
+ * buffers as written (extensions = 0).  With a bit set here:
+ *   SMOOTH_UNION  a union with smooth_radius k > 0 combines as min(a,b) - h*h*k/4, h = max(k-|a-b|,0)/k
+ *   BOX_FRAME     primitive op 5 is accepted: iq's box-frame distance of (dimension, thickness)
+ *   CLONE_REPAIR  uptree op 1 returns the LEFT branch (the one the clone's slot filled), so the lattice
+ *                 fold of downtree op 1 (faux_shader.rs:75-78) takes effect
+ * A tree in which an enabled extension occurs is evaluated exhaustively (bounds NONE, the general
+ * path): O(nodes) per query.  Restated by oracle/oracle.cpp under oracle_set_extensions. */
+typedef enum sdfgpu_extension {
+    SDFGPU_EXT_SMOOTH_UNION = 1,
+    SDFGPU_EXT_BOX_FRAME = 2,
+    SDFGPU_EXT_CLONE_REPAIR = 4
+} sdfgpu_extension;
+int sdfgpu_upload_tree_ext(sdfgpu_ctx* ctx, const SdfOperationBlock* dt,
+                           const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
+                           uint32_t layout, uint32_t bounds, uint32_t extensions);
+int sdfgpu_compact_host_ext(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
+                            uint32_t buffer_len, uint32_t layout, uint32_t bounds, uint32_t extensions,
+                            sdfgpu_tree_info* info, char* errbuf, size_t errlen);
 int sdfgpu_tree_info_get(const sdfgpu_ctx* ctx, sdfgpu_tree_info* out);
 /* The host half of sdfgpu_upload_tree alone (validation + compaction, no GPU
  * touched): same status codes, message copied into errbuf.  For producers

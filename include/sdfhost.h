@@ -43,6 +43,8 @@ const char* sdfhost_last_error(void);
 sdfhost_builder* sdfhost_primitive_sphere(float radius, const sdfhost_options* opts);
 /* SdfBuilder::primitive(SdfBox{half}) -- build-defined solid box, op 2 */
 sdfhost_builder* sdfhost_primitive_box(float hx, float hy, float hz, const sdfhost_options* opts);
+/* SdfBoxFrame (elements.rs:120-152; private and unfinished in the crate: op 5, dimension + thickness). */
+sdfhost_builder* sdfhost_primitive_box_frame(float dx, float dy, float dz, float thickness, const sdfhost_options* opts);
 /* .operation(SdfUnion{smooth_radius}) -- node.rs:396, elements.rs:157; consumes b */
 sdfhost_builder* sdfhost_operation_union(sdfhost_builder* b, float smooth_radius);
 /* SdfBuilder::operation(SdfCaaClone { displacement, neg_limit, pos_limit }) (elements.rs:215-262).

@@ -99,6 +99,28 @@ float mindist(const SdfBoundingBoxBlock& bb, V4 p) {
     return len4(qm) + rust_min(rust_max(q.x, rust_max(q.y, q.z)), 0.0f);
 }
 
+// ---- build-defined extensions (opt-in; default 0 = the crate as written) ----------------------
+// Mirrors sdfgpu_extension (include/sdfgpu.h).  The reference carries the data for all three but
+// evaluates none of them: smooth_radius is stored (elements.rs:207-211) and ignored (faux_shader.rs:87),
+// SdfBoxFrame has no distance formula and prim_dispatch panics on op 5 (elements.rs:120-152,
+// faux_shader.rs:65), and a clone subtree evaluates to +inf (faux_shader.rs:90).  Set by tests through
+// oracle_set_extensions; test infrastructure, not thread-safe against concurrent setters.
+enum { EXT_SMOOTH_UNION = 1, EXT_BOX_FRAME = 2, EXT_CLONE_REPAIR = 4 };
+uint32_t g_ext = 0;
+
+// Box frame (iq's sdBoxFrame, restated for op 5): b = dimension, e = thickness.
+//   p = |p| - b ; q = |p + e| - e ; the three edge-bar distances, then min(min(d0, d1), d2)
+inline float bar(float a, float b, float c) {   // |max(v,0)| + min(max(a, max(b, c)), 0) for v = (a, b, c)
+    float l = len3(sse_max(a, 0.f), sse_max(b, 0.f), sse_max(c, 0.f));
+    return l + rust_min(rust_max(a, rust_max(b, c)), 0.0f);
+}
+inline float box_frame(const float* dim, float e, V4 p) {
+    float px = std::fabs(p.x) - dim[0], py = std::fabs(p.y) - dim[1], pz = std::fabs(p.z) - dim[2];
+    float qx = std::fabs(px + e) - e, qy = std::fabs(py + e) - e, qz = std::fabs(pz + e) - e;
+    float d0 = bar(px, qy, qz), d1 = bar(qx, py, qz), d2 = bar(qx, qy, pz);
+    return fmin_local(fmin_local(d0, d1), d2);
+}
+
 // faux_shader.rs:60-67, plus the build-defined solid box (SURVEY C-7): the
 // box formula is the crate's own exact box SDF (obb.rs:297-299) on xyz with
 // the half extents in vec4s[0].
@@ -115,6 +137,10 @@ bool prim_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, V4 p, float* out
             *out = l + rust_min(rust_max(qx, rust_max(qy, qz)), 0.0f);
             return true;
         }
+        case SDF_PRIM_BOX_FRAME:
+            if (!(g_ext & EXT_BOX_FRAME)) return false;   // as written: panic
+            *out = box_frame(sp.vec4s[0].v, sp.floats[0], p);
+            return true;
         default:
             return false;  // panic!("Unsupported primitive op code")
     }
@@ -122,9 +148,11 @@ bool prim_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, V4 p, float* out
 
 // faux_shader.rs:69-82.  Clone (op 1): [p - d * clamp(round(p / d), lo, hi), ZERO], per lane
 // of the Vec4 (d.w = lo.w = hi.w = 0, so the w lane stays 1: 1/0 = inf, clamp to 0, 0*0 = 0).
-// glam's round / clamp are restated as roundf (half away from zero) and max-then-min; nothing
-// the state machine returns depends on these two points, because uptree op 1 discards the
-// value computed below a one-slot clone (see uptree_dispatch).
+// glam's SSE2 Vec4::round adds and subtracts 2^23 (the DirectXMath recipe), i.e. rounds half to even:
+// restated as nearbyintf in the default rounding mode; clamp = max-then-min.  As written nothing the
+// state machine returns depends on these points (uptree op 1 discards what a one-slot clone computed);
+// under EXT_CLONE_REPAIR they are what the clone's child is evaluated at.  From memory of glam 0.20:
+// unpinned like the rest of the glam arithmetic (file header).
 bool downtree_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, V4 p, V4 out[2]) {
     if (code == SDF_OP_UNION) {
         out[0] = p;
@@ -138,7 +166,7 @@ bool downtree_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, V4 p, V4 out
         const float in[4] = {p.x, p.y, p.z, p.w};
         float o[4];
         for (int k = 0; k < 4; ++k) {
-            float q = std::round(in[k] / d[k]);
+            float q = std::nearbyintf(in[k] / d[k]);
             q = sse_min(sse_max(q, lo[k]), hi[k]);
             o[k] = in[k] - d[k] * q;
         }
@@ -156,13 +184,28 @@ struct DI { float d; uint32_t id; };
 // Clone (op 1, :90) returns right_dist.  A one-slot node only ever fills branch_dists[0], so
 // the right one is still the +inf the frame was initialised with (:177): as written, a clone
 // subtree contributes +inf to its parent (SURVEY A-6).  Restated, not repaired.
-bool uptree_dispatch(uint32_t code, DI l, DI r, DI* out) {
+// Extensions: a union whose up-block carries smooth_radius k > 0 (elements.rs:207-211) combines with the
+// quadratic smooth minimum  min(a,b) - h*h*k/4, h = max(k - |a-b|, 0)/k  (one rounded operation per
+// step, in this order; the index is the smaller operand's, ties to the right as in the plain union);
+// a repaired clone hands up the branch its one slot filled.
+bool uptree_dispatch(uint32_t code, const SdfOpSpecificBlock& sp, DI l, DI r, DI* out) {
     if (code == SDF_OP_UNION) {
         *out = (l.d < r.d) ? l : r;
+        const float k = sp.floats[0];
+        if ((g_ext & EXT_SMOOTH_UNION) && k > 0.f) {
+            float diff = l.d - r.d;
+            float t = k - std::fabs(diff);
+            t = sse_max(t, 0.f);
+            float h = t / k;
+            float q = h * h;
+            q = q * k;
+            q = q * 0.25f;
+            out->d = out->d - q;
+        }
         return true;
     }
     if (code == SDF_OP_CAA_CLONE) {
-        *out = r;
+        *out = (g_ext & EXT_CLONE_REPAIR) ? l : r;
         return true;
     }
     return false;
@@ -201,7 +244,8 @@ int build_tree(Tree& t, const SdfOperationBlock* dt, const SdfOperationUptreeBlo
         if (lv > t.max_level) t.max_level = lv;
         t.parent[i] = (lv >= 2) ? at_level[lv - 1] : -1;
         at_level[lv] = (int32_t)i;
-        if ((!dt[i].is_primitive && dt[i].op_code == SDF_OP_CAA_CLONE) || (t.parent[i] >= 0 && t.dead[t.parent[i]]))
+        if ((!(g_ext & EXT_CLONE_REPAIR) && !dt[i].is_primitive && dt[i].op_code == SDF_OP_CAA_CLONE) ||
+            (t.parent[i] >= 0 && t.dead[t.parent[i]]))
             t.dead[i] = 1;
         if (dt[i].is_primitive) {
             t.prim_id[i] = (uint32_t)t.prim_node.size();
@@ -249,7 +293,7 @@ int faux_nearest_one(const Tree& t, V4 point, bool prune, Frame* stack, DI* out)
                 Frame& uf = stack[u.level];
                 if (uf.fill > 1) return -5;
                 DI r;
-                if (!uptree_dispatch(u.op_code, cf.d[0], cf.d[1], &r)) return -6;
+                if (!uptree_dispatch(u.op_code, u.op_specific, cf.d[0], cf.d[1], &r)) return -6;
                 uf.d[uf.fill] = r;                              // :146
                 uf.fill += 1;
                 last_ut_level = u.level;
@@ -286,7 +330,7 @@ int faux_nearest_one(const Tree& t, V4 point, bool prune, Frame* stack, DI* out)
         Frame& uf = stack[u.level];
         if (uf.fill > 1) return -5;
         DI r;
-        if (!uptree_dispatch(u.op_code, cf.d[0], cf.d[1], &r)) return -6;
+        if (!uptree_dispatch(u.op_code, u.op_specific, cf.d[0], cf.d[1], &r)) return -6;
         uf.d[uf.fill] = r;
         uf.fill += 1;
         ut_index += 1;
@@ -398,6 +442,13 @@ int parallel_for(size_t n, int threads, F&& fn) {
 }  // namespace
 
 extern "C" {
+
+// Opt-in extensions for the calls that follow (bit mask EXT_*; 0 = as written).  Returns the previous mask.
+uint32_t oracle_set_extensions(uint32_t mask) {
+    uint32_t old = g_ext;
+    g_ext = mask;
+    return old;
+}
 
 // n points through faux_shader::nearest_neighbor.  mode: 0 as written,
 // 1 pruning disabled, 2 tuned, 3 as written incl. the per-call allocation.

@@ -28,6 +28,25 @@ def lib():
     return _lib
 
 
+EXT_SMOOTH_UNION, EXT_BOX_FRAME, EXT_CLONE_REPAIR = 1, 2, 4
+
+
+class extensions:
+    """with O.extensions(O.EXT_SMOOTH_UNION | ...): the oracle evaluates the opt-in extensions."""
+
+    def __init__(self, mask):
+        self.mask = mask
+
+    def __enter__(self):
+        lib().oracle_set_extensions.restype = C.c_uint32
+        self.old = lib().oracle_set_extensions(C.c_uint32(self.mask))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_extensions(C.c_uint32(self.old))
+        return False
+
+
 def _tree_args(buf):
     n = buf.buffer_len
     return (C.c_void_p(buf.downtree_buffer.ctypes.data if n else None),

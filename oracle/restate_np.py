@@ -20,6 +20,16 @@ F = np.float32
 INF = F(np.inf)
 NO_PRIM = 0xFFFFFFFF
 
+# Opt-in, build-defined extensions (include/sdfgpu.h sdfgpu_extension); 0 = the crate as written.
+EXT_SMOOTH_UNION, EXT_BOX_FRAME, EXT_CLONE_REPAIR = 1, 2, 4
+EXT = 0
+
+
+def set_extensions(mask):
+    global EXT
+    old, EXT = EXT, int(mask)
+    return old
+
 
 def _mat4_mul_vec4(m, v):
     """glam Mat4 * Vec4 (faux_shader.rs:50,55,165,175).  m: 16 floats column-major; v: (..., 4)."""
@@ -95,6 +105,29 @@ def prim_value(op_code, op_specific, p):
         m = np.maximum(qx, m)
         m = np.minimum(m, zero)
         return (l + m).astype(F)
+    if op_code == 5 and (EXT & EXT_BOX_FRAME):
+        # box frame of (dimension b, thickness e): p = |p| - b, q = |p + e| - e, nearest of the three bar families
+        b = op_specific["vec4s"][0].astype(F)
+        e = F(op_specific["floats"][0])
+        px = np.abs(x) - b[0]
+        py = np.abs(y) - b[1]
+        pz = np.abs(z) - b[2]
+        qx = np.abs(px + e) - e
+        qy = np.abs(py + e) - e
+        qz = np.abs(pz + e) - e
+        zero = F(0.0)
+
+        def bar(a, bb, c):
+            l = _length3(np.where(a > 0, a, zero).astype(F), np.where(bb > 0, bb, zero).astype(F),
+                         np.where(c > 0, c, zero).astype(F))
+            m = np.maximum(bb, c)
+            m = np.maximum(a, m)
+            m = np.minimum(m, zero)
+            return (l + m).astype(F)
+
+        d0, d1, d2 = bar(px, qy, qz), bar(qx, py, qz), bar(qx, qy, pz)
+        d = np.where(d0 < d1, d0, d1)
+        return np.where(d < d2, d, d2).astype(F)
     raise ValueError(f"Unsupported primitive op code: {op_code}")
 
 
@@ -118,8 +151,14 @@ def leaf_chain(buf, pts):
         p = _mat4_mul_vec4(b["bounding_box"]["trans_inverse"].astype(F), frames[lv])
         if b["is_primitive"]:
             out.append(prim_value(int(b["op_code"]), b["op_specific"], p))
-        elif int(b["op_code"]) == 1:
+        elif int(b["op_code"]) == 1 and not (EXT & EXT_CLONE_REPAIR):
             dead_below = lv          # uptree op 1 returns the (never filled) right branch: +inf
+        elif int(b["op_code"]) == 1:
+            v = b["op_specific"]["vec4s"].astype(F)
+            with np.errstate(all="ignore"):
+                r = np.rint(p / v[0]).astype(F)
+                r = np.minimum(np.maximum(r, v[1]), v[2]).astype(F)
+                frames[lv + 1] = (p - v[0] * r).astype(F)
         else:
             frames[lv + 1] = p
     return np.array(out, F).reshape(len(out), len(pts))
@@ -139,7 +178,7 @@ def nearest_exhaustive(buf, pts):
     return best, idx
 
 
-def faux_nearest_scalar(buf, point):
+def faux_nearest_scalar(buf, point, prune=True):
     """faux_shader::nearest_neighbor (faux_shader.rs:96-208) as written, for ONE point: the literal state
     machine with its 256 frames, prune test and up-pass.  Pure-Python loop: small cases only."""
     dt, ut, n = buf.downtree_buffer, buf.uptree_buffer, buf.buffer_len
@@ -150,11 +189,22 @@ def faux_nearest_scalar(buf, point):
     dists[1] = [INF, INF]
     fill[1] = 0
 
-    def up(code, l, r):
+    def up(code, spec, l, r):
         if code == 0:
-            return l if l < r else r
+            m = l if l < r else r
+            k = F(spec["floats"][0])
+            if (EXT & EXT_SMOOTH_UNION) and k > 0:
+                with np.errstate(all="ignore"):
+                    t = k - np.abs(F(l - r))
+                    t = t if t > 0 else F(0.0)
+                    h = F(t / k)
+                    q = F(h * h)
+                    q = F(q * k)
+                    q = F(q * F(0.25))
+                    m = F(m - q)
+            return m
         if code == 1:
-            return r
+            return l if (EXT & EXT_CLONE_REPAIR) else r
         raise ValueError("Unsupported downtree op code")
 
     di = ui = last_level = 0
@@ -163,7 +213,7 @@ def faux_nearest_scalar(buf, point):
         lv = int(b["level"])
         p = pts[lv][fill[lv]]
         cmp_ = dists[lv][0]
-        if b["parent_is_union"]:
+        if prune and b["parent_is_union"]:      # prune=False: the exhaustive walk (the contract)
             m = mindist(b["bounding_box"], p.reshape(1, 4))[0]
             if m > 0 and (m > cmp_ or m > maxdist(b["other_box"], p.reshape(1, 4))[0]):
                 di += 1 + int(b["len"])
@@ -177,7 +227,7 @@ def faux_nearest_scalar(buf, point):
                 if ul >= last_ut:
                     break
                 l, r = dists[ul + 1]
-                dists[ul][fill[ul]] = up(int(u["op_code"]), l, r)
+                dists[ul][fill[ul]] = up(int(u["op_code"]), u["op_specific"], l, r)
                 fill[ul] += 1
                 last_ut = ul
                 ui += 1
@@ -206,7 +256,7 @@ def faux_nearest_scalar(buf, point):
         u = ut[ui]
         ul = int(u["level"])
         l, r = dists[ul + 1]
-        dists[ul][fill[ul]] = up(int(u["op_code"]), l, r)
+        dists[ul][fill[ul]] = up(int(u["op_code"]), u["op_specific"], l, r)
         fill[ul] += 1
         ui += 1
     return dists[1][0]

@@ -45,11 +45,12 @@ UT_DTYPE = np.dtype(
 assert OPSPEC_DTYPE.itemsize == 192 and BBOX_DTYPE.itemsize == 208
 assert DT_DTYPE.itemsize == 624 and UT_DTYPE.itemsize == 224
 
-PRIM_SPHERE, PRIM_BOX, OP_UNION, OP_CAA_CLONE = 0, 2, 0, 1
+PRIM_SPHERE, PRIM_BOX, PRIM_BOX_FRAME, OP_UNION, OP_CAA_CLONE = 0, 2, 5, 0, 1
 NO_PRIM = 0xFFFFFFFF
 
 BOUNDS_AUTO, BOUNDS_AABB, BOUNDS_OBB, BOUNDS_NONE, BOUNDS_BVH = 0, 1, 2, 3, 4
 LAYOUT_GLAM_SSE2 = 0
+EXT_SMOOTH_UNION, EXT_BOX_FRAME, EXT_CLONE_REPAIR = 1, 2, 4
 
 OK = 0
 ERR_INVALID_ARG, ERR_HIP, ERR_NO_TREE, ERR_LAYOUT, ERR_BAD_TREE = -1, -2, -3, -4, -5
@@ -73,6 +74,8 @@ class TreeInfo(C.Structure):
         ("device_bytes", C.c_uint64),
         ("scene_lo", C.c_float * 3),
         ("scene_hi", C.c_float * 3),
+        ("extensions", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -138,6 +141,8 @@ GPU_SYMBOLS = {
     "sdfgpu_sync": (_i, [_vp]),
     "sdfgpu_upload_tree": (_i, [_vp, _vp, _vp, _u32, _u32, _u32]),
     "sdfgpu_compact_host": (_i, [_vp, _vp, _u32, _u32, _u32, C.POINTER(TreeInfo), C.c_char_p, _sz]),
+    "sdfgpu_upload_tree_ext": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32]),
+    "sdfgpu_compact_host_ext": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(TreeInfo), C.c_char_p, _sz]),
     "sdfgpu_tree_info_get": (_i, [_vp, C.POINTER(TreeInfo)]),
     "sdfgpu_nearest": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sdfgpu_nearest_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
@@ -167,6 +172,7 @@ HOST_SYMBOLS = {
     "sdfhost_last_error": (C.c_char_p, []),
     "sdfhost_primitive_sphere": (_vp, [_f, C.POINTER(HostOptions)]),
     "sdfhost_primitive_box": (_vp, [_f, _f, _f, C.POINTER(HostOptions)]),
+    "sdfhost_primitive_box_frame": (_vp, [_f, _f, _f, _f, C.POINTER(HostOptions)]),
     "sdfhost_operation_union": (_vp, [_vp, _f]),
     "sdfhost_operation_caa_clone": (_vp, [_vp, _fp, _fp, _fp]),
     "sdfhost_with": (_vp, [_vp, _vp]),

@@ -363,11 +363,12 @@ int sdfgpu_sync(sdfgpu_ctx* c) {
 }
 
 // Host-only half of upload: validation + compaction, no GPU needed.
-int sdfgpu_compact_host(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
-                        uint32_t layout, uint32_t bounds, sdfgpu_tree_info* info, char* errbuf, size_t errlen) {
+int sdfgpu_compact_host_ext(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
+                            uint32_t layout, uint32_t bounds, uint32_t extensions, sdfgpu_tree_info* info, char* errbuf,
+                            size_t errlen) {
     CompactTree t;
     std::string err;
-    int rc = compact_tree(dt, ut, buffer_len, layout, bounds, &t, &err);
+    int rc = compact_tree(dt, ut, buffer_len, layout, bounds, extensions, &t, &err);
     if (info) *info = t.info;
     if (errbuf && errlen) {
         std::snprintf(errbuf, errlen, "%s", err.c_str());
@@ -375,12 +376,17 @@ int sdfgpu_compact_host(const SdfOperationBlock* dt, const SdfOperationUptreeBlo
     return rc;
 }
 
-int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
-                       uint32_t buffer_len, uint32_t layout, uint32_t bounds) {
+int sdfgpu_compact_host(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t buffer_len,
+                        uint32_t layout, uint32_t bounds, sdfgpu_tree_info* info, char* errbuf, size_t errlen) {
+    return sdfgpu_compact_host_ext(dt, ut, buffer_len, layout, bounds, 0u, info, errbuf, errlen);
+}
+
+int sdfgpu_upload_tree_ext(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
+                           uint32_t buffer_len, uint32_t layout, uint32_t bounds, uint32_t extensions) {
     if (!c) return SDFGPU_ERR_INVALID_ARG;
     CompactTree t;
     std::string err;
-    int rc = compact_tree(dt, ut, buffer_len, layout, bounds, &t, &err);
+    int rc = compact_tree(dt, ut, buffer_len, layout, bounds, extensions, &t, &err);
     if (rc != SDFGPU_OK) return set_err(c, rc, err);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -390,6 +396,7 @@ int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOper
     if ((rc = upload_vec(c, t.inner_obb, &c->tree.inner_obb)) != SDFGPU_OK) return rc;
     if ((rc = upload_vec(c, t.gen, &c->tree.gen)) != SDFGPU_OK) return rc;
     c->tree.n_gen = (uint32_t)t.gen.size();
+    c->tree.gen_eval = t.gen_eval;
     c->tree.root_ref = t.root_ref;
     c->tree.n_leaf = (uint32_t)t.leaves.size();
     c->tree.stack_depth = t.stack_depth;
@@ -403,6 +410,11 @@ int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOper
     c->has_tree = true;
     c->err.clear();
     return SDFGPU_OK;
+}
+
+int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
+                       uint32_t buffer_len, uint32_t layout, uint32_t bounds) {
+    return sdfgpu_upload_tree_ext(c, dt, ut, buffer_len, layout, bounds, 0u);
 }
 
 int sdfgpu_tree_info_get(const sdfgpu_ctx* c, sdfgpu_tree_info* out) {

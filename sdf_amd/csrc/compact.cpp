@@ -311,11 +311,13 @@ int fail(std::string* err, int code, const char* fmt, uint32_t a = 0, uint32_t b
 }  // namespace
 
 int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
-                 uint32_t layout, uint32_t bounds, CompactTree* out, std::string* err) {
+                 uint32_t layout, uint32_t bounds, uint32_t ext, CompactTree* out, std::string* err) {
     *out = CompactTree();
     if (layout != SDFGPU_LAYOUT_GLAM_SSE2)
         return fail(err, SDFGPU_ERR_LAYOUT, "unsupported record layout %u (only glam SSE2: 624/224-byte records)", layout);
     if (bounds > SDFGPU_BOUNDS_BVH) return fail(err, SDFGPU_ERR_INVALID_ARG, "unknown bounds mode %u", bounds);
+    if (ext & ~(uint32_t)(SDFGPU_EXT_SMOOTH_UNION | SDFGPU_EXT_BOX_FRAME | SDFGPU_EXT_CLONE_REPAIR))
+        return fail(err, SDFGPU_ERR_INVALID_ARG, "unknown extension bits in %u", ext);
     out->info.n_nodes = n;
     if (n == 0) {  // faux_shader.rs:104,207: empty buffer -> +inf
         out->info.bounds = bounds == SDFGPU_BOUNDS_AUTO ? (uint32_t)SDFGPU_BOUNDS_BVH : bounds;
@@ -343,6 +345,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     // (:162,177).  Its whole subtree is therefore "dead": validated, numbered, never resident.
     c.dead.assign(n, 0);
     uint32_t dead_end = 0;
+    uint32_t ext_in_use = 0;     // extensions that actually occur in the live part of this tree
     float margin_T = 0.f;
     double lip = 1.0;   // largest leaf Lipschitz constant (1 for rigid leaves)
     for (uint32_t i = 0; i < n; ++i) {
@@ -355,7 +358,10 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         if (b.is_primitive > 1 || b.parent_is_union > 1) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: bool field is not 0/1", i);
         if ((uint64_t)i + b.len >= n) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: len %u runs past the buffer", i, b.len);
         max_level = std::max(max_level, b.level);
-        if (!b.is_primitive && b.op_code == SDF_OP_CAA_CLONE) dead_end = std::max(dead_end, i + b.len + 1u);
+        if (!b.is_primitive && b.op_code == SDF_OP_CAA_CLONE) {
+            if (ext & SDFGPU_EXT_CLONE_REPAIR) ext_in_use |= (i < dead_end) ? 0u : (uint32_t)SDFGPU_EXT_CLONE_REPAIR;
+            else dead_end = std::max(dead_end, i + b.len + 1u);
+        }
         const bool dead = i < dead_end;
         c.dead[i] = dead ? 1 : 0;
         if (!dead) max_level_live = std::max(max_level_live, b.level);
@@ -372,6 +378,14 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                     if (!std::isfinite(h)) return fail(err, SDFGPU_ERR_NON_FINITE, "primitive %u: non-finite half extent", i);
                     margin_T = std::max(margin_T, std::fabs(h));
                 }
+            } else if (b.op_code == SDF_PRIM_BOX_FRAME && (ext & SDFGPU_EXT_BOX_FRAME)) {
+                for (int a = 0; a < 3; ++a) {
+                    float h = b.op_specific.vec4s[0].v[a];
+                    if (!std::isfinite(h)) return fail(err, SDFGPU_ERR_NON_FINITE, "primitive %u: non-finite dimension", i);
+                    margin_T = std::max(margin_T, std::fabs(h));
+                }
+                if (!std::isfinite(b.op_specific.floats[0])) return fail(err, SDFGPU_ERR_NON_FINITE, "primitive %u: non-finite thickness", i);
+                if (!dead) ext_in_use |= SDFGPU_EXT_BOX_FRAME;
             } else {
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported primitive op code: %u (node %u)", b.op_code, i);
             }
@@ -410,6 +424,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         if (c.dead[i]) c.live[i] = 0;
     }
     // ---- the uptree buffer must be the post-order of the same tree ----
+    std::vector<float> node_smooth;
     {
         std::vector<uint32_t> stack, post;
         post.reserve(n);
@@ -431,23 +446,40 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             st.pop_back();
         }
         if (post.size() != n) return fail(err, SDFGPU_ERR_BAD_TREE, "tree does not cover the buffer");
+        node_smooth.assign(n, 0.f);
         for (uint32_t j = 0; j < n; ++j) {
             const SdfOperationBlock& b = dt[post[j]];
             if (ut[j].level != b.level || ut[j].op_code != b.op_code)
                 return fail(err, SDFGPU_ERR_BAD_TREE, "uptree block %u does not match downtree node %u", j, post[j]);
+            // union up-blocks carry the smooth radius (elements.rs:207-211); in effect only under the extension
+            if (!b.is_primitive && b.op_code == SDF_OP_UNION && (ext & SDFGPU_EXT_SMOOTH_UNION) && !c.dead[post[j]]) {
+                const float k = ut[j].op_specific.floats[0];
+                if (!std::isfinite(k)) return fail(err, SDFGPU_ERR_NON_FINITE, "union node %u: non-finite smooth radius", post[j]);
+                if (k > 0.f) { node_smooth[post[j]] = k; ext_in_use |= SDFGPU_EXT_SMOOTH_UNION; }
+            }
         }
     }
 
-    if (!identity_inner || !exact_rows) {
+    out->info.extensions = ext_in_use;
+    if (!identity_inner || !exact_rows || ext_in_use) {
         // General path: no pruning, the literal per-level point chain.
         if (bounds == SDFGPU_BOUNDS_AABB || bounds == SDFGPU_BOUNDS_OBB || bounds == SDFGPU_BOUNDS_BVH)
             return fail(err, SDFGPU_ERR_BAD_TREE,
-                        "pruned bounds need identity internal trans_inverse and affine leaf rows; use AUTO or NONE");
+                        "pruned bounds need identity internal trans_inverse, affine leaf rows and no extension in effect; use AUTO or NONE");
         if (max_level_live > GEN_MAX_LEVELS)
             return fail(err, SDFGPU_ERR_TOO_DEEP, "general path holds %u levels, tree has %u", GEN_MAX_LEVELS, max_level_live);
+        if ((ext_in_use & SDFGPU_EXT_SMOOTH_UNION) && max_level_live > GEN_EVAL_MAX_LEVELS)
+            return fail(err, SDFGPU_ERR_TOO_DEEP, "smooth-union evaluation holds %u levels, tree has %u", GEN_EVAL_MAX_LEVELS,
+                        max_level_live);
         out->gen.reserve(n);
+        std::vector<uint32_t> gen_of(n, REF_NONE);   // node -> index in the resident array
+        std::vector<uint32_t> parent_of(n, REF_NONE);
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k : {c.child0[i], c.child1[i]})
+                if (k != REF_NONE) parent_of[k] = i;
         for (uint32_t i = 0; i < n; ++i) {
-            if (c.dead[i]) continue;   // clone subtrees contribute +inf: left out of the walk
+            if (c.dead[i]) continue;   // clone subtrees contribute +inf as written: left out of the walk
+            gen_of[i] = (uint32_t)out->gen.size();
             out->gen.emplace_back();
             GpuGenNode& g = out->gen.back();
             std::memset(&g, 0, sizeof g);
@@ -457,11 +489,30 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             g.len = dt[i].len;
             g.kind = dt[i].op_code;
             g.prim = c.prim_id[i];
+            const uint32_t par = parent_of[i];
+            g.parent = par == REF_NONE ? REF_NONE : gen_of[par];
+            g.slot = (par != REF_NONE && c.child1[par] == i) ? 1u : 0u;
             if (dt[i].is_primitive) {
                 if (dt[i].op_code == SDF_PRIM_SPHERE) g.param[0] = dt[i].op_specific.floats[0];
                 else for (int a = 0; a < 3; ++a) g.param[a] = dt[i].op_specific.vec4s[0].v[a];
+                if (dt[i].op_code == SDF_PRIM_BOX_FRAME) g.param[3] = dt[i].op_specific.floats[0];
+            } else {
+                g.op = dt[i].op_code == SDF_OP_CAA_CLONE ? GEN_OP_CLONE : GEN_OP_UNION;
+                g.smooth_k = node_smooth[i];
+                if (g.op == GEN_OP_CLONE)
+                    for (int v = 0; v < 3; ++v)
+                        for (int a = 0; a < 3; ++a) g.clone[3 * v + a] = dt[i].op_specific.vec4s[v].v[a];
             }
         }
+        // n_up: every live internal node is combined right after the last live node of its subtree
+        for (uint32_t i = 0; i < n; ++i) {
+            if (c.dead[i] || dt[i].is_primitive) continue;
+            uint32_t last = i;
+            for (uint32_t k = i + 1; k <= i + dt[i].len; ++k)
+                if (!c.dead[k]) last = k;
+            out->gen[gen_of[last]].n_up += 1;
+        }
+        out->gen_eval = (ext_in_use & SDFGPU_EXT_SMOOTH_UNION) != 0;
         sdfgpu_tree_info& gi = out->info;
         gi.n_prims = n_prims;
         gi.n_inner = n_inner;

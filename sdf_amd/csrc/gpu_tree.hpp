@@ -58,20 +58,30 @@ static_assert(sizeof(GpuInnerObb) == 128, "GpuInnerObb is two 64-byte lines");
 // pre-order with its full 4x4 trans_inverse, walked exhaustively with a
 // per-level point stack -- the literal point chain of faux_shader.rs:160-178.
 constexpr uint32_t GEN_MAX_LEVELS = 32;
+constexpr uint32_t GEN_EVAL_MAX_LEVELS = 24;   // with the per-level results in LDS as well (walk_eval): 2 KB per level per wavefront
+constexpr uint32_t GEN_OP_UNION = 0, GEN_OP_CLONE = 1;
 struct alignas(64) GpuGenNode {
     float m[16];       // trans_inverse, column-major as in the buffer
-    float param[3];
+    float param[4];    // sphere: radius; box: half extents; box frame: dimension + thickness
     uint32_t kind;     // primitive kind (leaves)
     uint32_t is_leaf;
     uint32_t level;    // root = 1
     uint32_t prim;     // primitive id (leaves)
     uint32_t len;
-    uint32_t pad[8];
+    // evaluation with the real post-order combine (extensions; walk_eval in kernels.hip)
+    uint32_t slot;     // which of its parent's two results this node writes (child ordinal in the buffer)
+    uint32_t parent;   // index of the parent in this array (REF_NONE for the root)
+    uint32_t n_up;     // internal nodes whose subtree ends with this node: combined right after it, deepest first
+    uint32_t op;       // internal nodes: GEN_OP_*
+    float smooth_k;    // union: smooth radius in effect (0 = plain min)
+    float clone[9];    // clone: displacement, neg_limit, pos_limit (xyz each)
+    uint32_t pad[9];
 };
-static_assert(sizeof(GpuGenNode) == 128, "GpuGenNode is two 64-byte lines");
+static_assert(sizeof(GpuGenNode) == 192, "GpuGenNode is three 64-byte lines");
 
 struct CompactTree {
     std::vector<GpuGenNode> gen;        // general path (empty otherwise)
+    bool gen_eval = false;              // general path must run the post-order combine (a smooth union is in effect)
     std::vector<GpuLeaf> leaves;
     std::vector<GpuInner> inner;        // AABB mode
     std::vector<GpuInnerObb> inner_obb; // OBB mode
@@ -88,6 +98,6 @@ struct CompactTree {
 // sdfgpu_status; on failure `err` has the detail.  Pure host code (testable
 // without a GPU through sdfgpu_compact_host).
 int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut, uint32_t n,
-                 uint32_t layout, uint32_t bounds, CompactTree* out, std::string* err);
+                 uint32_t layout, uint32_t bounds, uint32_t extensions, CompactTree* out, std::string* err);
 
 }  // namespace sdfgpu

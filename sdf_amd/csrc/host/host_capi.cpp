@@ -62,6 +62,12 @@ sdfhost_builder* sdfhost_primitive_box(float hx, float hy, float hz, const sdfho
     });
 }
 
+sdfhost_builder* sdfhost_primitive_box_frame(float dx, float dy, float dz, float thickness, const sdfhost_options* opts) {
+    return guard([&]() -> sdfhost_builder* {
+        return new sdfhost_builder{SdfBuilder::primitive(std::make_unique<SdfBoxFrame>(Vec3(dx, dy, dz), thickness), to_opts(opts))};
+    });
+}
+
 sdfhost_builder* sdfhost_operation_union(sdfhost_builder* b, float smooth_radius) {
     if (!b) return nullptr;
     return guard([&]() -> sdfhost_builder* {

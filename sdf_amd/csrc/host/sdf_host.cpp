@@ -386,6 +386,19 @@ ExpandedSdfNode SdfBox::expand(const SdfNode& node, const BuildOptions&) const {
     return ExpandedSdfNode::primitive(node.bbox.value(), clone());
 }
 
+SdfBoundingBox SdfBoxFrame::get_bbox(const std::vector<SdfBoundingBox>&, const BuildOptions&) const {
+    return SdfBoundingBox::from_transform(Transform::from_scale(dimension));   // elements.rs:131-133
+}
+SdfOpSpecificBlock SdfBoxFrame::get_dt_specific_block() const {                // elements.rs:142-147
+    SdfOpSpecificBlock b = zero_block();
+    b.vec4s[0].v[0] = dimension.x; b.vec4s[0].v[1] = dimension.y; b.vec4s[0].v[2] = dimension.z; b.vec4s[0].v[3] = 0.f;
+    b.floats[0] = thickness;
+    return b;
+}
+ExpandedSdfNode SdfBoxFrame::expand(const SdfNode& node, const BuildOptions&) const {
+    return ExpandedSdfNode::primitive(node.bbox.value(), clone());
+}
+
 SdfOpSpecificBlock SdfUnion::get_ut_specific_block() const {
     SdfOpSpecificBlock b = zero_block();
     b.floats[0] = smooth_radius;                                 // elements.rs:207-211

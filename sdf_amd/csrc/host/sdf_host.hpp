@@ -124,6 +124,21 @@ struct SdfBox : SdfElement {
     ExpandedSdfNode expand(const SdfNode& node, const BuildOptions& o) const override;
 };
 
+// elements.rs:120-152: the crate's private, unfinished box frame (op 5).  As there: bounding box from
+// the dimension, dimension + thickness in the op-specific block, and NO distance_to override, so the
+// recursive query sees the trait default |p| (elements.rs:72-74).  The flat query of the crate panics
+// on it (faux_shader.rs:65); the GPU path evaluates it only under SDFGPU_EXT_BOX_FRAME.
+struct SdfBoxFrame : SdfElement {
+    Vec3 dimension;
+    float thickness;
+    SdfBoxFrame(Vec3 d, float t) : dimension(d), thickness(t) {}
+    SdfElementInfo get_info() const override { return SdfElementInfo::primitive_info(SDF_PRIM_BOX_FRAME); }
+    SdfBoundingBox get_bbox(const std::vector<SdfBoundingBox>&, const BuildOptions&) const override;
+    std::unique_ptr<SdfElement> clone() const override { return std::make_unique<SdfBoxFrame>(dimension, thickness); }
+    SdfOpSpecificBlock get_dt_specific_block() const override;
+    ExpandedSdfNode expand(const SdfNode& node, const BuildOptions& o) const override;
+};
+
 // elements.rs:157-212
 struct SdfUnion : SdfElement {
     float smooth_radius;

@@ -1027,6 +1027,44 @@ __device__ __forceinline__ P4 mat4_mul(const float* __restrict__ c, P4 p) {
     return r;
 }
 
+// Box frame (build-defined extension, primitive op 5; the crate carries dimension + thickness but no
+// formula, elements.rs:120-152): iq's sdBoxFrame, one rounded operation per step, restated by
+// oracle.cpp::box_frame.
+__device__ __forceinline__ float bar_value(float a, float b, float c) {
+    const float ma = a > 0.f ? a : 0.f, mb = b > 0.f ? b : 0.f, mc = c > 0.f ? c : 0.f;
+    const float l = __builtin_sqrtf((ma * ma + mb * mb) + mc * mc);
+    return l + __builtin_fminf(__builtin_fmaxf(a, __builtin_fmaxf(b, c)), 0.0f);
+}
+__device__ __forceinline__ float prim_value_gen(uint32_t kind, const float* __restrict__ pr, float lx, float ly, float lz) {
+    if (kind == SDF_PRIM_BOX_FRAME) {
+        const float e = pr[3];
+        const float px = __builtin_fabsf(lx) - pr[0], py = __builtin_fabsf(ly) - pr[1], pz = __builtin_fabsf(lz) - pr[2];
+        const float qx = __builtin_fabsf(px + e) - e, qy = __builtin_fabsf(py + e) - e, qz = __builtin_fabsf(pz + e) - e;
+        const float d0 = bar_value(px, qy, qz), d1 = bar_value(qx, py, qz), d2 = bar_value(qx, qy, pz);
+        return min_nn(min_nn(d0, d1), d2);
+    }
+    return prim_value(kind, pr[0], pr[1], pr[2], lx, ly, lz);
+}
+
+// downtree_dispatch (faux_shader.rs:69-82): union hands the point down; clone folds it onto the lattice,
+// p - d * clamp(round(p / d), lo, hi) per component (round = half to even, glam's SSE2 recipe).  The w
+// lane: d.w = lo.w = hi.w = 0, so 1/0 = inf is clamped to 0 and w stays what it was.
+__device__ __forceinline__ float fold1(float p, float d, float lo, float hi) {
+    float q = __builtin_rintf(p / d);
+    q = q > lo ? q : lo;    // _mm_max_ps(q, lo): second operand when q is NaN
+    q = q < hi ? q : hi;
+    return p - d * q;
+}
+__device__ __forceinline__ P4 down_point(const GpuGenNode* __restrict__ N, P4 r) {
+    if (N->op != GEN_OP_CLONE) return r;
+    P4 o;
+    o.x = fold1(r.x, N->clone[0], N->clone[3], N->clone[6]);
+    o.y = fold1(r.y, N->clone[1], N->clone[4], N->clone[7]);
+    o.z = fold1(r.z, N->clone[2], N->clone[5], N->clone[8]);
+    o.w = fold1(r.w, 0.f, 0.f, 0.f);
+    return o;
+}
+
 // only: SDF_NO_PRIM = every primitive, else just that one (normal taps).
 template <class Acc>
 __device__ __forceinline__ void walk_general(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, uint32_t only,
@@ -1038,18 +1076,104 @@ __device__ __forceinline__ void walk_general(const GpuGenNode* __restrict__ node
         const float4 q4 = stk[(lv - 1u) * 64u + lane];
         const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
         if (N->is_leaf) {
-            const float d = prim_value(N->kind, N->param[0], N->param[1], N->param[2], r.x, r.y, r.z);
+            const float d = prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
             if (only == SDF_NO_PRIM || only == N->prim) acc.offer(d, N->prim);
         } else {
-            stk[lv * 64u + lane] = make_float4(r.x, r.y, r.z, r.w);   // downtree_dispatch, union: [p, p]
+            const P4 c = down_point(N, r);   // downtree_dispatch: union [p, p]; clone [lattice point, 0]
+            stk[lv * 64u + lane] = make_float4(c.x, c.y, c.z, c.w);
         }
     }
 }
 
+// The same walk with the reference's post-order combine carried out for real (uptree_dispatch,
+// faux_shader.rs:84-94, over the frames of :141-151): needed as soon as a combine is not a plain
+// minimum, i.e. when a union's smooth radius is in effect (SDFGPU_EXT_SMOOTH_UNION).  Every node writes
+// its (distance, index) into slot `slot` of its parent's level; an internal node is combined right after
+// the last node of its subtree.  No pruning, so the order of evaluation is the same for every lane and
+// the only per-lane state is the point and the two results of each level, in LDS.
+//   smooth union: min(a,b) - h*h*k/4 with h = max(k - |a-b|, 0)/k; index of the smaller operand, ties to
+//   the right like the plain union (`if a < b {a} else {b}`, faux_shader.rs:27-29).
+struct EvalStacks {
+    float4* pt;     // [levels + 1][64]
+    float2* d;      // [levels + 2][64]
+    uint2* id;      // [levels + 2][64]
+};
+__device__ __forceinline__ void walk_eval(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, const EvalStacks& S,
+                                          uint32_t lane, float& out_d, uint32_t& out_id) {
+    S.pt[lane] = make_float4(p.x, p.y, p.z, p.w);
+    S.d[64u + lane] = make_float2(__builtin_inff(), __builtin_inff());     // frame of level 1 (faux_shader.rs:102-106)
+    S.id[64u + lane] = make_uint2(SDF_NO_PRIM, SDF_NO_PRIM);
+    for (uint32_t i = 0; i < n; ++i) {
+        const GpuGenNode* __restrict__ N = nodes + i;
+        const uint32_t lv = N->level;
+        const float4 q4 = S.pt[(lv - 1u) * 64u + lane];
+        const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+        uint32_t a;
+        if (N->is_leaf) {
+            const float v = prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
+            float2 dd = S.d[lv * 64u + lane];
+            uint2 ii = S.id[lv * 64u + lane];
+            if (N->slot) { dd.y = v; ii.y = N->prim; } else { dd.x = v; ii.x = N->prim; }
+            S.d[lv * 64u + lane] = dd;
+            S.id[lv * 64u + lane] = ii;
+            a = N->parent;
+        } else {
+            const P4 c = down_point(N, r);
+            S.pt[lv * 64u + lane] = make_float4(c.x, c.y, c.z, c.w);
+            S.d[(lv + 1u) * 64u + lane] = make_float2(__builtin_inff(), __builtin_inff());   // :177
+            S.id[(lv + 1u) * 64u + lane] = make_uint2(SDF_NO_PRIM, SDF_NO_PRIM);
+            a = i;   // an internal node with nothing live below it is combined at once
+        }
+        for (uint32_t u = 0; u < N->n_up; ++u) {
+            const GpuGenNode* __restrict__ A = nodes + a;
+            const uint32_t la = A->level;
+            const float2 c = S.d[(la + 1u) * 64u + lane];
+            const uint2 ci = S.id[(la + 1u) * 64u + lane];
+            float v;
+            uint32_t vi;
+            if (A->op == GEN_OP_CLONE) {   // reached only when the clone is repaired: the branch its one slot filled
+                v = c.x;
+                vi = ci.x;
+            } else {
+                const bool left = c.x < c.y;
+                v = left ? c.x : c.y;
+                vi = left ? ci.x : ci.y;
+                const float k = A->smooth_k;
+                if (k > 0.f) {
+                    float t = k - __builtin_fabsf(c.x - c.y);
+                    t = t > 0.f ? t : 0.f;
+                    const float h = t / k;
+                    float q = h * h;
+                    q = q * k;
+                    q = q * 0.25f;
+                    v = v - q;
+                }
+            }
+            float2 dd = S.d[la * 64u + lane];
+            uint2 ii = S.id[la * 64u + lane];
+            if (A->slot) { dd.y = v; ii.y = vi; } else { dd.x = v; ii.x = vi; }
+            S.d[la * 64u + lane] = dd;
+            S.id[la * 64u + lane] = ii;
+            a = A->parent;
+        }
+    }
+    out_d = S.d[64u + lane].x;
+    out_id = S.id[64u + lane].x;
+}
+
+__device__ __forceinline__ EvalStacks eval_stacks(float4* base, uint32_t levels) {
+    EvalStacks S;
+    S.pt = base;
+    S.d = reinterpret_cast<float2*>(base + (size_t)(levels + 1u) * 64u);
+    S.id = reinterpret_cast<uint2*>(S.d + (size_t)(levels + 2u) * 64u);
+    return S;
+}
+
 template <int K>
 __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __restrict__ nodes, uint32_t n_nodes,
-                                                           const float4* __restrict__ pts, uint32_t n, uint32_t k,
-                                                           float* __restrict__ out_dist, uint32_t* __restrict__ out_prim) {
+                                                           uint32_t eval_levels, const float4* __restrict__ pts, uint32_t n,
+                                                           uint32_t k, float* __restrict__ out_dist,
+                                                           uint32_t* __restrict__ out_prim) {
     extern __shared__ float4 gstk[];
     const uint32_t lane = threadIdx.x;
     const uint32_t i = blockIdx.x * 64u + lane;
@@ -1057,6 +1181,16 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[i];
     if constexpr (K == 1) {
+        if (eval_levels) {   // a combine that is not a plain minimum is in effect: the real post-order evaluation
+            float d;
+            uint32_t id;
+            walk_eval(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, eval_stacks(gstk, eval_levels), lane, d, id);
+            if (alive) {
+                out_dist[i] = d;
+                if (out_prim) out_prim[i] = id;
+            }
+            return;
+        }
         AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
         walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
@@ -1079,7 +1213,7 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
 }
 
 __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __restrict__ nodes, uint32_t n_nodes,
-                                                            sdfgpu_camera cam, uint32_t width, uint32_t height,
+                                                            uint32_t eval_levels, sdfgpu_camera cam, uint32_t width, uint32_t height,
                                                             sdfgpu_march_params mp, uint32_t tile_first, uint32_t tile_stride,
                                                             uint32_t tile_count, uint32_t row_major,
                                                             uint8_t* __restrict__ o_hit, float* __restrict__ o_depth,
@@ -1107,7 +1241,8 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         if (alive) { px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t; }
         AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
-        walk_general(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (eval_levels) walk_eval(nodes, n_nodes, P4{px, py, pz, 1.0f}, eval_stacks(gstk, eval_levels), lane, acc.best, acc.bid);
+        else walk_general(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
             if (acc.best < mp.eps_hit) { hit = true; hit_prim = acc.bid; alive = false; }
             else { t = t + acc.best; if (t > mp.t_max) alive = false; }
@@ -1224,7 +1359,14 @@ static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const 
     return hipGetLastError();
 }
 
-static size_t general_lds(const DeviceTree& d) { return (size_t)(d.stack_depth + 1u) * 64u * sizeof(float4); }
+// LDS of the general path: one float4 per level per lane; with the post-order combine, also the two
+// results (distance, index) of every level.
+static uint32_t general_eval_levels(const DeviceTree& d) { return d.gen_eval ? d.stack_depth : 0u; }
+static size_t general_lds(const DeviceTree& d) {
+    size_t b = (size_t)(d.stack_depth + 1u) * 64u * sizeof(float4);
+    if (d.gen_eval) b += (size_t)(d.stack_depth + 2u) * 64u * (sizeof(float2) + sizeof(uint2));
+    return b;
+}
 
 hipError_t launch_box_bounds(const SdfBoundingBoxBlock* d_box, const float* d_pts, uint32_t n, float* d_min, float* d_max,
                              hipStream_t s) {
@@ -1237,8 +1379,8 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t*
                           uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s, bool stats_asm_walk) {
     if (d.gen) {   // general path: exhaustive literal chain (no counters, no reordering needed)
         if (n == 0) return hipSuccess;
-        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, (const float4*)pts, n, 1,
-                                                                                       out_dist, out_prim);
+        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d),
+                                                                                       (const float4*)pts, n, 1, out_dist, out_prim);
         return hipGetLastError();
     }
     if (st) return stats_asm_walk ? launch_nearest_t<2>(d, pts, order, n, out_dist, out_prim, st, s)
@@ -1269,10 +1411,10 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
         dim3 grid((n + 63u) / 64u), block(64);
         const size_t lds = general_lds(d);
         const float4* p4 = (const float4*)pts;
-        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
-        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
-        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
-        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, p4, n, k, out_dist, out_prim);
+        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
+        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
+        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
+        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
         return hipGetLastError();
     }
     const bool obb = d.bounds == SDFGPU_BOUNDS_OBB;
@@ -1335,7 +1477,7 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s) {
     if (tile_count == 0) return hipSuccess;
     if (d.gen) {
-        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, cam, w, h, mp, tile_first,
+        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), cam, w, h, mp, tile_first,
                                                                                 tile_stride, tile_count, row_major ? 1u : 0u,
                                                                                 hit, depth, normal, prim);
         return hipGetLastError();

@@ -15,6 +15,7 @@ struct DeviceTree {
     GpuInnerObb* inner_obb = nullptr;
     GpuGenNode* gen = nullptr;          // general path: all nodes, pre-order
     uint32_t n_gen = 0;
+    bool gen_eval = false;              // general path runs the post-order combine (smooth union in effect)
     uint32_t root_ref = REF_NONE;
     uint32_t n_leaf = 0;
     uint32_t stack_depth = 1;

@@ -29,15 +29,15 @@ def march_params(max_steps=128, eps_hit=1e-3, t_min=0.0, t_max=1e3, normal_h=1e-
     return _ffi.MarchParams(max_steps, eps_hit, t_min, t_max, normal_h, 0)
 
 
-def compact_host(buf, bounds=_ffi.BOUNDS_AUTO, layout=_ffi.LAYOUT_GLAM_SSE2):
+def compact_host(buf, bounds=_ffi.BOUNDS_AUTO, layout=_ffi.LAYOUT_GLAM_SSE2, extensions=0):
     """Validation + compaction only (no GPU): returns (status, TreeInfo, message)."""
     lib = _ffi.load_library()
     info = _ffi.TreeInfo()
     err = C.create_string_buffer(512)
-    rc = lib.sdfgpu_compact_host(
+    rc = lib.sdfgpu_compact_host_ext(
         buf.downtree_buffer.ctypes.data if buf.buffer_len else None,
         buf.uptree_buffer.ctypes.data if buf.buffer_len else None,
-        buf.buffer_len, layout, bounds, C.byref(info), err, 512,
+        buf.buffer_len, layout, bounds, extensions, C.byref(info), err, 512,
     )
     return rc, info, err.value.decode()
 
@@ -69,14 +69,15 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_sync(self._h))
 
     # ---- tree -----------------------------------------------------------
-    def upload_tree(self, buf: SdfTreeBuffer, bounds=_ffi.BOUNDS_AUTO, layout=_ffi.LAYOUT_GLAM_SSE2):
+    def upload_tree(self, buf: SdfTreeBuffer, bounds=_ffi.BOUNDS_AUTO, layout=_ffi.LAYOUT_GLAM_SSE2, extensions=0):
+        """extensions: EXT_* bits (0 = evaluate the buffer as the crate is written)."""
         n = buf.buffer_len
         self._check(
-            self._lib.sdfgpu_upload_tree(
+            self._lib.sdfgpu_upload_tree_ext(
                 self._h,
                 buf.downtree_buffer.ctypes.data if n else None,
                 buf.uptree_buffer.ctypes.data if n else None,
-                n, layout, bounds,
+                n, layout, bounds, extensions,
             )
         )
         return self.info()

@@ -118,6 +118,18 @@ class SdfBox:
         return math.sqrt(sum(max(v, 0.0) ** 2 for v in q)) + min(max(q), 0.0)
 
 
+class SdfBoxFrame:
+    """elements.rs:120-152 (primitive op 5; private and unfinished in the crate: it has no distance
+    formula there, so distance_to is the trait default |p|)."""
+
+    def __init__(self, dimension, thickness):
+        self.dimension = tuple(float(v) for v in dimension)
+        self.thickness = float(thickness)
+
+    def distance_to(self, p):
+        return math.sqrt(sum(float(v) ** 2 for v in p))
+
+
 class SdfUnion:
     """elements.rs:157-212 (operation op 0)."""
 
@@ -249,6 +261,8 @@ class SdfBuilder:
             h = lib.sdfhost_primitive_sphere(prim.radius, _opts(opts))
         elif isinstance(prim, SdfBox):
             h = lib.sdfhost_primitive_box(*prim.half, _opts(opts))
+        elif isinstance(prim, SdfBoxFrame):
+            h = lib.sdfhost_primitive_box_frame(*prim.dimension, prim.thickness, _opts(opts))
         else:
             raise SdfError("not a primitive")  # node.rs:377 assert
         if not h:
