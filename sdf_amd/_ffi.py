@@ -58,7 +58,7 @@ ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE, ER
 COMM_ID_BYTES = 128
 MAX_K = 16
 STATIC_MAX_POINTS = 262144
-OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER, OPT_STATS_ASM_WALK = 0, 1, 2, 3, 4
+OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER, OPT_STATS_ASM_WALK, OPT_QUERY_PIPELINE = 0, 1, 2, 3, 4, 5
 
 
 class TreeInfo(C.Structure):

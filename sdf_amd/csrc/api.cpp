@@ -54,6 +54,15 @@ struct sdfgpu_ctx {
     std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
     bool reorder = true;
     bool stats_asm_walk = false;    // SDFGPU_OPT_STATS_ASM_WALK
+    // Large query batches: the batch is cut into chunks, and the Morton sort of chunk i + 1 (bandwidth-bound,
+    // on the helper stream) runs beside the walk of chunk i (VALU-bound, on the caller's stream).
+    uint32_t query_chunks = 0;      // SDFGPU_OPT_QUERY_PIPELINE (0 / 1: off, the default: measured slower)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_start = nullptr;
+    struct PipeSet {
+        DevBuf keys_a, keys_b, idx_a, idx_b, tmp;
+        hipEvent_t sorted = nullptr, walked = nullptr;
+    } pipe[2];
     float skip_ext_opt = 0.f;    // SDFGPU_OPT_SKIP_EXTENSION as set (< 0: half the mean primitive size)
     float mean_extent = 0.f;
     // sdfgpu_nearest_dev_static: address of sort.hip's file-scope scratch array on this device
@@ -157,6 +166,62 @@ int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const
     return SDFGPU_OK;
 }
 
+
+// Reordered query over a large batch, chunked and overlapped (see sdfgpu_ctx::query_chunks).  `launch`
+// walks one chunk: launch(first point of the chunk, permutation of the chunk or nullptr, points in the
+// chunk, index of its first point in the batch).  Everything the caller's stream has to wait for is
+// expressed with events, so the call stays asynchronous and can be captured in a graph.
+constexpr size_t PIPELINE_MIN_POINTS = 1u << 20;
+template <class F>
+int ordered_query(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, F&& launch) {
+    const bool pipelined = c->reorder && !c->tree.gen && c->query_chunks > 1 && n >= PIPELINE_MIN_POINTS;
+    if (!pipelined) {
+        const uint32_t* order = nullptr;
+        int rc = make_order(c, d_pts, n, s, &order);
+        if (rc) return rc;
+        return launch(d_pts, order, n, (size_t)0);
+    }
+    if (!c->aux) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+        for (auto& ps : c->pipe) {
+            HIP_TRY(c, hipEventCreateWithFlags(&ps.sorted, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&ps.walked, hipEventDisableTiming));
+        }
+    }
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        float cen = 0.5f * (c->info.scene_lo[a] + c->info.scene_hi[a]);
+        float half = (c->info.scene_hi[a] - c->info.scene_lo[a]) + 1.0f;
+        lo[a] = cen - half;
+        hi[a] = cen + half;
+    }
+    const size_t chunk = (((n + c->query_chunks - 1) / c->query_chunks) + 255) & ~(size_t)255;
+    const size_t tmp = sort_temp_bytes((uint32_t)chunk);
+    for (auto& ps : c->pipe) {
+        int rc;
+        if ((rc = reserve(c, ps.keys_a, chunk * 4)) || (rc = reserve(c, ps.keys_b, chunk * 4)) || (rc = reserve(c, ps.idx_a, chunk * 4)) ||
+            (rc = reserve(c, ps.idx_b, chunk * 4)) || (rc = reserve(c, ps.tmp, tmp)))
+            return rc;
+    }
+    // the helper stream starts after everything already queued on the caller's stream (the inputs)
+    HIP_TRY(c, hipEventRecord(c->ev_start, s));
+    HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_start, 0));
+    size_t first = 0;
+    for (uint32_t k = 0; first < n; ++k, first += chunk) {
+        sdfgpu_ctx::PipeSet& ps = c->pipe[k & 1];
+        const size_t m = n - first < chunk ? n - first : chunk;
+        if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->aux, ps.walked, 0));   // the walk two chunks back has let go of this set
+        HIP_TRY(c, launch_morton_order(d_pts + 4 * first, (uint32_t)m, lo, hi, (uint32_t*)ps.keys_a.p, (uint32_t*)ps.keys_b.p,
+                                       (uint32_t*)ps.idx_a.p, (uint32_t*)ps.idx_b.p, ps.tmp.p, sort_temp_bytes((uint32_t)m), c->aux));
+        HIP_TRY(c, hipEventRecord(ps.sorted, c->aux));
+        HIP_TRY(c, hipStreamWaitEvent(s, ps.sorted, 0));
+        int rc = launch(d_pts + 4 * first, (const uint32_t*)ps.idx_b.p, m, first);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(ps.walked, s));
+    }
+    return SDFGPU_OK;
+}
 
 // Pass boundaries of the multi-pass march for a given step budget, and the
 // scratch it needs.  Default schedule: survivors thin out quickly at first and
@@ -345,6 +410,17 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
     for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats, &c->keys_a, &c->keys_b, &c->idx_a,
                       &c->idx_b, &c->sort_tmp})
         if (b->p) (void)hipFree(b->p);
+    if (c->aux) {
+        (void)hipStreamSynchronize(c->aux);
+        for (auto& ps : c->pipe) {
+            for (DevBuf* b : {&ps.keys_a, &ps.keys_b, &ps.idx_a, &ps.idx_b, &ps.tmp})
+                if (b->p) (void)hipFree(b->p);
+            if (ps.sorted) (void)hipEventDestroy(ps.sorted);
+            if (ps.walked) (void)hipEventDestroy(ps.walked);
+        }
+        if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+        (void)hipStreamDestroy(c->aux);
+    }
     for (auto& m : c->march) {
         if (m.buf.p) (void)hipFree(m.buf.p);
         if (m.order.p) (void)hipFree(m.order.p);
@@ -430,10 +506,11 @@ int sdfgpu_nearest_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, float* d_dis
     if (n == 0) return SDFGPU_OK;
     if (!d_pts || !d_dist) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null device pointer");
     if (n > 0x7FFFFFFFull) return set_err(c, SDFGPU_ERR_TOO_LARGE, "more than 2^31-1 points in one call");
-    const uint32_t* order = nullptr;
-    if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order))) return rc;
-    HIP_TRY(c, launch_nearest(c->tree, d_pts, order, (uint32_t)n, d_dist, d_prim, nullptr, (hipStream_t)stream));
-    return SDFGPU_OK;
+    return ordered_query(c, d_pts, n, (hipStream_t)stream, [&](const float* p, const uint32_t* order, size_t m, size_t first) -> int {
+        HIP_TRY(c, launch_nearest(c->tree, p, order, (uint32_t)m, d_dist + first, d_prim ? d_prim + first : nullptr, nullptr,
+                                  (hipStream_t)stream));
+        return SDFGPU_OK;
+    });
 }
 
 // The allocation-free variant of sdfgpu_nearest_dev: same kernels, same results; the reordering
@@ -530,6 +607,10 @@ int sdfgpu_set_option(sdfgpu_ctx* c, int option, double value) {
         case SDFGPU_OPT_COMPACTION:
             c->compaction = value != 0.0;
             return SDFGPU_OK;
+        case SDFGPU_OPT_QUERY_PIPELINE:
+            if (!(value >= 0.0 && value <= 16.0)) return set_err(c, SDFGPU_ERR_INVALID_ARG, "query pipeline chunks must be in 0..16");
+            c->query_chunks = (uint32_t)value;
+            return SDFGPU_OK;
         case SDFGPU_OPT_STATS_ASM_WALK:
             c->stats_asm_walk = value != 0.0;
             return SDFGPU_OK;
@@ -549,10 +630,10 @@ int sdfgpu_knn_dev(sdfgpu_ctx* c, const float* d_pts, size_t n, uint32_t k, floa
     if (n == 0) return SDFGPU_OK;
     if (!d_pts || !d_dist || !d_prim) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null device pointer");
     if (n > 0x7FFFFFFFull / k) return set_err(c, SDFGPU_ERR_TOO_LARGE, "n * k exceeds 2^31-1 in one call");
-    const uint32_t* order = nullptr;
-    if ((rc = make_order(c, d_pts, n, (hipStream_t)stream, &order))) return rc;
-    HIP_TRY(c, launch_knn(c->tree, d_pts, order, (uint32_t)n, k, d_dist, d_prim, nullptr, (hipStream_t)stream));
-    return SDFGPU_OK;
+    return ordered_query(c, d_pts, n, (hipStream_t)stream, [&](const float* p, const uint32_t* order, size_t m, size_t first) -> int {
+        HIP_TRY(c, launch_knn(c->tree, p, order, (uint32_t)m, k, d_dist + first * k, d_prim + first * k, nullptr, (hipStream_t)stream));
+        return SDFGPU_OK;
+    });
 }
 
 int sdfgpu_knn(sdfgpu_ctx* c, const float* pts, size_t n, uint32_t k, float* out_dist, uint32_t* out_prim) {

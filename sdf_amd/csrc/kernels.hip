@@ -683,12 +683,26 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     WaveCounters wc;
     nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
     if (alive) {
+        // whole rows as 16-byte stores when the row is exactly K wide (rows are K * 4 bytes apart, so they
+        // are aligned when the arrays are)
+        bool rows = false;
+        if constexpr (K % 4 == 0) rows = k == (uint32_t)K && ((((uintptr_t)out_dist) | ((uintptr_t)out_prim)) & 15u) == 0;
+        if (rows) {
+            float4* od = reinterpret_cast<float4*>(out_dist + (size_t)src * K);
+            uint4* op = reinterpret_cast<uint4*>(out_prim + (size_t)src * K);
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            if ((uint32_t)j < k) {
-                out_dist[(size_t)src * k + j] = acc.dist(j);
-                out_prim[(size_t)src * k + j] = acc.prim(j);
+            for (int j = 0; j + 3 < K; j += 4) {
+                od[j / 4] = make_float4(acc.dist(j), acc.dist(j + 1), acc.dist(j + 2), acc.dist(j + 3));
+                op[j / 4] = make_uint4(acc.prim(j), acc.prim(j + 1), acc.prim(j + 2), acc.prim(j + 3));
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if ((uint32_t)j < k) {
+                    out_dist[(size_t)src * k + j] = acc.dist(j);
+                    out_prim[(size_t)src * k + j] = acc.prim(j);
+                }
+        }
     }
     if constexpr (COUNT) flush_counters(wc, lane, 0, 0, st);
 }

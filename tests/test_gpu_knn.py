@@ -69,3 +69,39 @@ def test_reordering_is_invisible(gpu):
     assert np.array_equal(bits(k_on[0]), bits(k_off[0])) and np.array_equal(k_on[1], k_off[1])
     d0, i0 = O.nearest(buf, pts, O.MODE_TUNED, threads=8)
     assert np.array_equal(bits(d_on), bits(d0)) and np.array_equal(i_on, i0)
+
+
+def test_chunked_pipeline_is_invisible(gpu):
+    # batches of >= 2^20 points are cut into chunks whose Morton sort overlaps the previous chunk's walk
+    # (SDFGPU_OPT_QUERY_PIPELINE); results must not depend on the chunking, including a ragged last chunk
+    import torch
+    from sdf_amd import _ffi
+
+    n_prims, n = 2000, (1 << 20) + 12345
+    buf = S.random_scene_buffer(n_prims, 0x91E)
+    gpu.upload_tree(buf)
+    pts = torch.from_numpy(make_points(n, S.default_extent(n_prims), seed=77)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for chunks in (0, 4, 3):
+            gpu.set_option(_ffi.OPT_QUERY_PIPELINE, chunks)
+            d1 = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+            i1 = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+            d8 = torch.full((n * 8,), -1.0, dtype=torch.float32, device="cuda")
+            i8 = torch.full((n * 8,), -1, dtype=torch.int32, device="cuda")
+            for _ in range(2):      # twice: the second call reuses scratch sets and events of the first
+                gpu.nearest_dev(pts.data_ptr(), n, d1.data_ptr(), i1.data_ptr(), stream)
+                gpu.knn_dev(pts.data_ptr(), n, 8, d8.data_ptr(), i8.data_ptr(), stream)
+            torch.cuda.synchronize()
+            res[chunks] = (d1, i1, d8, i8)
+    finally:
+        gpu.set_option(_ffi.OPT_QUERY_PIPELINE, 0)
+    for chunks in (4, 3):
+        for a, b in zip(res[0], res[chunks]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"chunks={chunks}"
+    # and against the oracle on a sample
+    sel = np.arange(0, n, 4099)
+    d0, i0 = O.nearest(buf, pts[sel].cpu().numpy(), O.MODE_TUNED, threads=8)
+    assert np.array_equal(bits(res[4][0][sel].cpu().numpy()), bits(d0))
+    assert np.array_equal(res[4][1][sel].cpu().numpy().view(np.uint32), i0)
