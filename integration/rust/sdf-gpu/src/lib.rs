@@ -54,6 +54,9 @@ pub struct TreeInfo {
     pub device_bytes: u64,
     pub scene_lo: [f32; 3],
     pub scene_hi: [f32; 3],
+    /// `sdfgpu_extension` bits in effect in this tree (0 = evaluated as the crate is written)
+    pub extensions: u32,
+    pub reserved: u32,
 }
 
 pub const LAYOUT_GLAM_SSE2: u32 = 0;
@@ -64,6 +67,22 @@ pub const OPT_REORDER: i32 = 0;
 pub const OPT_SKIP_EXTENSION: i32 = 1;
 pub const OPT_COMPACTION: i32 = 2;
 pub const OPT_TILE_ORDER: i32 = 3;
+pub const OPT_STATS_ASM_WALK: i32 = 4;
+pub const OPT_QUERY_PIPELINE: i32 = 5;
+/// `sdfgpu_extension`: opt-in evaluation of data the crate carries but never evaluates
+/// (elements.rs:207-211 smooth_radius, elements.rs:120-152 SdfBoxFrame, faux_shader.rs:90 clone).
+pub const EXT_SMOOTH_UNION: u32 = 1;
+pub const EXT_BOX_FRAME: u32 = 2;
+pub const EXT_CLONE_REPAIR: u32 = 4;
+/// `sdfgpu_nearest_dev_static` takes at most this many points per call.
+pub const STATIC_MAX_POINTS: usize = 262_144;
+pub const COMM_ID_BYTES: usize = 128;
+
+/// Opaque `sdfgpu_comm` (an RCCL communicator of the library, one rank per process).
+#[repr(C)]
+pub struct Comm {
+    _private: [u8; 0],
+}
 
 extern "C" {
     fn sdfgpu_create(device_id: c_int, out: *mut *mut Ctx) -> c_int;
@@ -71,7 +90,23 @@ extern "C" {
     fn sdfgpu_last_error(ctx: *const Ctx) -> *const c_char;
     fn sdfgpu_upload_tree(ctx: *mut Ctx, dt: *const SdfOperationBlock, ut: *const SdfOperationUptreeBlock,
                           buffer_len: u32, layout: u32, bounds: u32) -> c_int;
+    fn sdfgpu_upload_tree_ext(ctx: *mut Ctx, dt: *const SdfOperationBlock, ut: *const SdfOperationUptreeBlock,
+                              buffer_len: u32, layout: u32, bounds: u32, extensions: u32) -> c_int;
     fn sdfgpu_tree_info_get(ctx: *const Ctx, out: *mut TreeInfo) -> c_int;
+    pub fn sdfgpu_nearest_dev(ctx: *mut Ctx, d_pts_xyzw: *const f32, n: usize, d_out_dist: *mut f32,
+                              d_out_prim: *mut u32, stream: *mut c_void) -> c_int;
+    /// allocation-free variant (no reference counterpart): scratch in a static __device__ array
+    pub fn sdfgpu_nearest_dev_static(ctx: *mut Ctx, d_pts_xyzw: *const f32, n: usize, d_out_dist: *mut f32,
+                                     d_out_prim: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn sdfgpu_knn_dev(ctx: *mut Ctx, d_pts_xyzw: *const f32, n: usize, k: u32, d_out_dist: *mut f32,
+                          d_out_prim: *mut u32, stream: *mut c_void) -> c_int;
+    // multi-GPU framebuffer assembly: one process per GPU, RCCL grouped send/recv to `root`
+    pub fn sdfgpu_comm_get_id(ctx: *mut Ctx, id_out: *mut u8) -> c_int;
+    pub fn sdfgpu_comm_create(ctx: *mut Ctx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut Comm) -> c_int;
+    pub fn sdfgpu_comm_destroy(comm: *mut Comm);
+    pub fn sdfgpu_render_frame_comm(ctx: *mut Ctx, comm: *mut Comm, cam: *const Camera, width: u32, height: u32,
+                                    mp: *const MarchParams, root: c_int, d_hit: *mut u8, d_depth: *mut f32,
+                                    d_normal_xyz: *mut f32, d_prim: *mut u32, stream: *mut c_void) -> c_int;
     fn sdfgpu_nearest(ctx: *mut Ctx, pts_xyzw: *const f32, n: usize, out_dist: *mut f32, out_prim: *mut u32) -> c_int;
     fn sdfgpu_knn(ctx: *mut Ctx, pts_xyzw: *const f32, n: usize, k: u32, out_dist: *mut f32, out_prim: *mut u32) -> c_int;
     fn sdfgpu_box_bounds(ctx: *mut Ctx, bbox: *const SdfBoundingBoxBlock, pts_xyzw: *const f32, n: usize,
@@ -123,6 +158,24 @@ impl GpuTree {
         };
         if rc != 0 {
             return Err(this.fail(rc)); // `this` drops and frees the context
+        }
+        Ok(this)
+    }
+
+    /// The same with opt-in extensions (`EXT_*` bits); 0 = `upload`.
+    pub fn upload_ext(device: i32, tree: &SdfTreeBuffer, extensions: u32) -> Result<Self, Error> {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe { sdfgpu_create(device, &mut ctx) };
+        if rc != 0 {
+            return Err(Error(rc, "sdfgpu_create failed".into()));
+        }
+        let this = GpuTree { ctx };
+        let rc = unsafe {
+            sdfgpu_upload_tree_ext(ctx, tree.downtree_buffer.as_ptr(), tree.uptree_buffer.as_ptr(), tree.buffer_len,
+                                   LAYOUT_GLAM_SSE2, BOUNDS_AUTO, extensions)
+        };
+        if rc != 0 {
+            return Err(this.fail(rc));
         }
         Ok(this)
     }

@@ -95,6 +95,28 @@ __global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) 
         } else if constexpr (KIND == 14) {  // 32 VALU with an SGPR operand and abs (VOP3)
             REP8(asm volatile("v_sub_f32 %0, |%0|, %5\n v_sub_f32 %2, |%2|, %6\n v_sub_f32 %3, |%3|, %5\n v_sub_f32 %4, |%4|, %6"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "s"(s0), "s"(s1));)
+        } else if constexpr (KIND == 15) {  // 32 64-bit unsigned compares
+            unsigned long long q0 = ((unsigned long long)__float_as_uint(a0) << 32) | s0, q1 = ((unsigned long long)__float_as_uint(a1) << 32) | s1;
+            REP8(asm volatile("v_cmp_lt_u64 vcc, %0, %1\n v_cmp_lt_u64 vcc, %1, %0\n v_cmp_gt_u64 vcc, %0, %1\n v_cmp_gt_u64 vcc, %1, %0"
+                              : : "v"(q0), "v"(q1) : "vcc");)
+        } else if constexpr (KIND == 16) {  // 32 32-bit unsigned compares
+            unsigned q0 = __float_as_uint(a0), q1 = __float_as_uint(a1);
+            REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %0\n v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %1, %0"
+                              : : "v"(q0), "v"(q1) : "vcc");)
+        } else if constexpr (KIND == 17) {  // 32 v_cndmask (vcc)
+            REP8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %1, vcc\n v_cndmask_b32 %3, %3, %1, vcc\n v_cndmask_b32 %4, %4, %1, vcc"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : : );)
+        } else if constexpr (KIND == 18) {  // 32 v_cndmask, mask in an SGPR pair (VOP3)
+            unsigned long long mk = 0x5555aaaa5555aaaaull ^ s0;
+            REP8(asm volatile("v_cndmask_b32 %0, %0, %1, %5\n v_cndmask_b32 %2, %2, %1, %5\n v_cndmask_b32 %3, %3, %1, %5\n v_cndmask_b32 %4, %4, %1, %5"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "s"(mk));)
+        } else if constexpr (KIND == 19) {  // 32 v_cndmask (vcc), vcc set by a scalar move first
+            asm volatile("s_mov_b64 vcc, 0x55555555" ::: "vcc");
+            REP8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %1, vcc\n v_cndmask_b32 %3, %3, %1, vcc\n v_cndmask_b32 %4, %4, %1, vcc"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : : );)
+        } else if constexpr (KIND == 20) {  // compare + 2 selects, as a compare-exchange does
+            REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_cndmask_b32 %3, %1, %0, vcc\n v_add_f32 %4, %4, %2"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");)
         } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
             REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
         }
@@ -151,6 +173,12 @@ int main() {
     run<12>("32 v_pk_*_f16", 32, 0);
     run<13>("32 v_pk_*_f16 sgpr src", 32, 0);
     run<14>("32 v_sub |a|, sgpr (VOP3)", 32, 0);
+    run<15>("32 v_cmp_*_u64", 32, 0);
+    run<16>("32 v_cmp_*_u32", 32, 0);
+    run<17>("32 v_cndmask_b32", 32, 0);
+    run<18>("32 v_cndmask sgpr mask", 32, 0);
+    run<19>("32 v_cndmask vcc (s_mov)", 32, 0);
+    run<20>("cmp + 2 cndmask + add", 32, 0);
     run<2>("32 VALU + 32 SALU", 32, 32);
     run<3>("32 VALU + 16 SALU", 32, 16);
     return 0;
