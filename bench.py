@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the N-rank path)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for every rank (rehearsal: N ranks on one GPU); default LOCAL_RANK")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: assemble with torch.distributed all-gather instead of the library's communicator")
+    ap.add_argument("--no-variants", action="store_true", help="skip the variants leg (profiling: kernel averages then cover the timed frames only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
     ap.add_argument("--knn-points", type=int, default=10_000_000)
@@ -597,7 +598,8 @@ def main():
                 "queries": st["queries"],
                 "needed_over_issued_lane_slots": st["inner_needed"] / max(1, 64 * st["wave_inner"]),
             }
-            line["variants"] = variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev)
+            if not a.no_variants:
+                line["variants"] = variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev)
             if not a.no_cpu:
                 line["cpu_baseline"] = cpu_baseline(buf, cam, mp, w, h, a.cpu_seconds)
     knn = None

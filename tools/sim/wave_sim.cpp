@@ -118,7 +118,7 @@ static void walk(Lane* L, Stats& st) {
     int ndrive = 0;
     for (int i = 0; i < 64; ++i) {
         ndrive += L[i].drive;
-        float bp = std::fmax(L[i].best + L[i].mg, 0.f) + g_ext;
+        float bp = (std::fmax(L[i].best + L[i].mg, 0.f) + g_ext) * T.box_scale;
         L[i].thr = bp * bp * 1.0006f;
     }
     uint64_t inner0 = st.wave_inner;
@@ -131,8 +131,9 @@ static void walk(Lane* L, Stats& st) {
             int n0 = 0, nt = 0;
             st.wave_inner++;
             for (int i = 0; i < 64; ++i) {
-                k0[i] = aabb_d2(N.c0, N.h0, L[i].px, L[i].py, L[i].pz);
-                k1[i] = aabb_d2(N.c1, N.h1, L[i].px, L[i].py, L[i].pz);
+                const float sc = T.box_scale;   // box records are stored scaled (compact.cpp)
+                k0[i] = aabb_d2(N.c0, N.h0, L[i].px * sc, L[i].py * sc, L[i].pz * sc);
+                k1[i] = aabb_d2(N.c1, N.h1, L[i].px * sc, L[i].py * sc, L[i].pz * sc);
                 if (!L[i].drive) continue;
                 st.lane_inner++;
                 bool m0 = k0[i] <= L[i].thr, m1 = k1[i] <= L[i].thr;
@@ -175,7 +176,7 @@ static void walk(Lane* L, Stats& st) {
                         if (l.second < l.third) l.third = l.second;
                         l.second = d; l.sid = id;
                     } else if (d < l.third) l.third = d;
-                    float bp = std::fmax(l.best + l.mg, 0.f);
+                    float bp = std::fmax(l.best + l.mg, 0.f) * T.box_scale;
                     l.thr = bp * bp * 1.0006f;
                     continue;
                 }
@@ -184,7 +185,7 @@ static void walk(Lane* L, Stats& st) {
                 float loser = b ? L[i].best : d;
                 if (rival && loser < L[i].second) { L[i].second = loser; L[i].sid = b ? L[i].bid : id; }
                 if (b) { L[i].best = d; L[i].bid = id; }
-                float bp = std::fmax(L[i].best + L[i].mg, 0.f) + g_ext;
+                float bp = (std::fmax(L[i].best + L[i].mg, 0.f) + g_ext) * T.box_scale;
                 L[i].thr = bp * bp * 1.0006f;
             }
         }
@@ -255,7 +256,7 @@ static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finis
         if (!l.alive) continue;
         if (deferring && l.drive) continue;   // waits: same point next time
         if (do_walk) {
-            float lb = std::fmin(std::sqrt(l.lbk) * 0.9996f, g_k2 ? l.third : l.second) - l.mg;
+            float lb = std::fmin(std::sqrt(l.lbk) / T.box_scale * 0.9996f, g_k2 ? l.third : l.second) - l.mg;
             l.budget = l.certified ? std::fmax(l.budget, lb) : lb;
         }
         l.steps++;
@@ -289,7 +290,7 @@ int main(int argc, char** argv) {
     sdfhost_expanded* ex = sdfhost_expanded_new(node, nullptr);
     sdfhost_buffer* buf = sdfhost_make_buffer(ex, nullptr);
     std::string err;
-    int rc = compact_tree(sdfhost_buffer_downtree(buf), sdfhost_buffer_uptree(buf), sdfhost_buffer_len(buf), 0, SDFGPU_BOUNDS_AUTO, &T, &err);
+    int rc = compact_tree(sdfhost_buffer_downtree(buf), sdfhost_buffer_uptree(buf), sdfhost_buffer_len(buf), 0, SDFGPU_BOUNDS_AUTO, 0u, &T, &err);
     if (rc) { fprintf(stderr, "compact: %s\n", err.c_str()); return 1; }
     g_lip = T.lipschitz;
     float L = sdfhost_default_extent(n_prims);
@@ -357,6 +358,13 @@ int main(int argc, char** argv) {
     printf("inner/walk %.1f lane_inner/lane_walk %.1f needed/lane_walk %.1f  VALU est %.3fe9\n", (double)st.wave_inner / st.wave_walks,
            (double)st.lane_inner / st.lane_walks, (double)st.lane_needed / st.lane_walks, st.valu() / 1e9);
     printf("leading single-child chain: %.2f inner visits per walk\n", (double)st.chain_inner / st.wave_walks);
+    if (strat == "tile")
+        for (int nr : {2, 4, 8}) {   // round-robin tile deal over nr ranks: heaviest rank against the mean
+            std::vector<double> sum(nr, 0.0);
+            double tot = 0;
+            for (size_t t = 0; t < wave_cost.size(); ++t) { sum[t % nr] += wave_cost[t]; tot += wave_cost[t]; }
+            printf("round-robin over %d ranks: heaviest share / mean share = %.4f\n", nr, *std::max_element(sum.begin(), sum.end()) / (tot / nr));
+        }
     std::sort(wave_cost.begin(), wave_cost.end());
     printf("waves %zu  max wave VALU %.0f  p99 %.0f  median %.0f\n", wave_cost.size(), wave_cost.back(),
            wave_cost[wave_cost.size() * 99 / 100], wave_cost[wave_cost.size() / 2]);
