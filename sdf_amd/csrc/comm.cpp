@@ -123,7 +123,7 @@ int staging_for(sdfgpu_comm* m, hipStream_t stream, size_t nbytes, bool root, St
         }
         s->stream = stream;
     }
-    if (s->nbytes != nbytes || (root && !s->gathered)) {
+    if (s->nbytes != nbytes || (root && m->world > 1 && !s->gathered)) {
         hipStream_t keep = s->stream;
         if (s->mine && hipStreamSynchronize(keep) != hipSuccess) (void)hipDeviceSynchronize();
         release(*s);

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         s += adv ? 1u : 0u;
         state = hit_now ? 1u : ((go & (tn > mp.t_max)) ? 2u : state);
         if (!cheap) {   // the walk may have changed `last`: fetch its record once
-            if ((state == 0u) & (s < pa.step_end)) {
+            if ((state == 0u) & (s < pa.step_end) & (last != SDF_NO_PRIM)) {   // (an empty tree has no nearest primitive)
                 const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
                 c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
             }

@@ -56,6 +56,10 @@ def test_render_empty_scene_all_miss(gpu):
     img = gpu.render(cam, 32, 16, mp)
     assert img["hit"].sum() == 0 and np.all(np.isposinf(img["depth"])) and np.all(img["prim"] == S.NO_PRIM)
     assert np.all(img["normal"] == 0)
+    # no far plane either: every ray marches all its steps through an empty scene and still ends as a miss
+    mp2 = S.march_params(max_steps=16, eps_hit=1e-3, t_min=0.0, t_max=float("inf"), normal_h=1e-4)
+    img = gpu.render(cam, 32, 16, mp2)
+    assert img["hit"].sum() == 0 and np.all(img["prim"] == S.NO_PRIM)
 
 
 def test_sphere_normal_points_outward(gpu):
