@@ -7,9 +7,12 @@ primitive synthetic scene (seed 0x5DF00003).  A "step" is one full frame.
 
   N = 1 : one sdfgpu_render_dev launch per step.
   N > 1 : the frame's 8x8 tiles are dealt round-robin to the ranks (rank r
-          renders tiles r, r+N, ...), the tile-compact planes are packed and
-          all-gathered over RCCL, rank 0 scatters them into the frame.  The
-          total work per step is fixed, so scaling is "strong".
+          renders tiles r, r+N, ...), the tile-compact planes go to rank 0 over
+          RCCL (the library's communicator: grouped ncclSend / ncclRecv; if it
+          cannot be made, a torch.distributed all-gather) and rank 0 scatters
+          them into the frame.  Several frames are in flight on separate streams,
+          since 1/N of a frame does not fill a GPU.  The total work per step is
+          fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  `value` = rays (pixels) per second, whole job.
 """
@@ -20,7 +23,29 @@ import sys
 import time
 
 import numpy as np
-import torch
+
+
+def _hw_queues_before_hip():
+    """A rank's share of an N-rank frame (1/N of the tiles) no longer fills its GPU, so frames
+    overlap on separate streams (`frames_in_flight`); HIP maps streams onto GPU_MAX_HW_QUEUES
+    hardware queues (4 by default) and launches that share a queue run one after the other.
+    Measured on one MI355X with rank 0's share of 8 (--emulate-world 8 --pipeline 8): 4 queues
+    0.37 ms per frame, 8: 0.33, 16: 0.25 (an eighth of the whole-frame kernel is 0.24).  The
+    runtime reads the variable when it initialises, i.e. it has to be set before the first HIP call."""
+    want = 0
+    for i, arg in enumerate(sys.argv):
+        if arg == "--hw-queues" and i + 1 < len(sys.argv):
+            want = int(sys.argv[i + 1])
+        elif arg.startswith("--hw-queues="):
+            want = int(arg.split("=", 1)[1])
+    if want == 0 and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--emulate-world" in sys.argv):
+        want = 16
+    if want > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(want, 32))
+
+
+_hw_queues_before_hip()
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -49,6 +74,9 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=0,
                     help="frames in flight (1 = strictly one after the other; 0 = default: 2 on one GPU, "
                          "min(8, N + 2) on N GPUs, where a rank's tile share no longer fills its GPU)")
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="GPU_MAX_HW_QUEUES for this process (0 = leave the environment's value on one GPU, 16 on N > 1 "
+                         "GPUs where several frames' launches have to overlap; at most 32)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="diagnostic (1 GPU): render only rank 0's tile share of an N-rank frame, no gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the N-rank path)")
@@ -568,6 +596,7 @@ def main():
                 "max_steps": int(mp.max_steps), "eps_hit": float(mp.eps_hit), "t_max": float(mp.t_max),
                 "normal_h": float(mp.normal_h),
                 "frames_in_flight": depth,
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                 "tile_order": not a.no_tile_order,
                 "camera": "static (every frame the same view; the longest-first tile order is learned from the previous frame)",
                 "partition": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + {gather_kind}",
