@@ -8,11 +8,16 @@
 #include "gpu_tree.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
+#include <thread>
+
+#include <sched.h>
 
 namespace sdfgpu {
 namespace {
@@ -219,84 +224,173 @@ Box3 empty_box() { return Box3{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFI
 // `budget` = inner levels this subtree may still use (the per-wave stack of the kernels and
 // their LDS footprint are sized by it): a split is only eligible when both sides still fit a
 // balanced tree of budget-1 levels; when no SAH candidate does, the set is halved at the median.
-uint32_t build_sah(std::vector<PrimBox>& p, uint32_t lo, uint32_t hi, uint32_t budget, CompactTree& out, Box3* box,
-                   uint32_t* depth) {
-    if (hi - lo == 1) {
-        *box = p[lo].b;
-        *depth = 0;
-        return REF_LEAF | p[lo].id;
-    }
-    constexpr int NB = 16;
-    const uint64_t cap = budget - 1 >= 32 ? (1ull << 32) : (1ull << (budget - 1));   // budget >= 1 here
-    double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = lo; i < hi; ++i)
-        for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], p[i].c[a]); cmax[a] = std::max(cmax[a], p[i].c[a]); }
-    int best_axis = -1, best_bin = 0;
-    double best_cost = INFINITY;
-    for (int a = 0; a < 3; ++a) {
-        const double ext = cmax[a] - cmin[a];
-        if (!(ext > 0.0)) continue;
-        Box3 bb[NB];
-        uint32_t cnt[NB] = {0};
-        for (auto& b : bb) b = empty_box();
-        const double sc = NB / ext;
-        for (uint32_t i = lo; i < hi; ++i) {
-            int k = std::min(NB - 1, (int)((p[i].c[a] - cmin[a]) * sc));
-            cnt[k]++;
-            grow(bb[k], p[i].b);
+//
+// Records are written in pre-order into an array sized beforehand (a subtree of m primitives has
+// m - 1 internal nodes, so the right child of a node at index s whose left side holds ml primitives
+// sits at s + ml): subtrees own disjoint ranges of both the primitive array and the record array, so
+// the two sides of the upper levels are built by separate threads and the result is the same array,
+// byte for byte, whatever the thread count.
+struct SahBuild {
+    std::vector<PrimBox>& p;
+    GpuInner* inner;
+    static constexpr int NB = 16;
+    static constexpr uint32_t FORK_MIN = 4096;   // primitives below which a side is not worth a thread
+
+    uint32_t node(uint32_t lo, uint32_t hi, uint32_t budget, uint32_t self, int forks, Box3* box, uint32_t* depth) {
+        if (hi - lo == 1) {
+            *box = p[lo].b;
+            *depth = 0;
+            return REF_LEAF | p[lo].id;
         }
-        double ra[NB];
-        uint32_t rn[NB];
-        Box3 acc = empty_box();
-        uint32_t n = 0;
-        for (int k = NB - 1; k > 0; --k) { grow(acc, bb[k]); n += cnt[k]; ra[k] = n ? half_area(acc) : 0.0; rn[k] = n; }
-        acc = empty_box();
-        n = 0;
-        for (int k = 0; k < NB - 1; ++k) {
-            grow(acc, bb[k]);
-            n += cnt[k];
-            if (n == 0 || rn[k + 1] == 0 || n > cap || rn[k + 1] > cap) continue;
-            const double cost = half_area(acc) * n + ra[k + 1] * rn[k + 1];
-            if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+        const uint32_t mid = split(lo, hi, budget);
+        Box3 b0{}, b1{};
+        uint32_t d0 = 0, d1 = 0, r0 = 0, r1 = 0;
+        const uint32_t self0 = self + 1, self1 = self + (mid - lo);
+        bool forked = false;
+        if (forks > 0 && mid - lo >= FORK_MIN && hi - mid >= FORK_MIN) {
+            std::thread left;
+            try {
+                left = std::thread([&] { r0 = node(lo, mid, budget - 1, self0, forks - 1, &b0, &d0); });
+                forked = true;
+            } catch (const std::system_error&) {   // no thread to be had: build both sides here
+            }
+            if (forked) {
+                r1 = node(mid, hi, budget - 1, self1, forks - 1, &b1, &d1);
+                left.join();
+            }
         }
+        if (!forked) {
+            r0 = node(lo, mid, budget - 1, self0, forks, &b0, &d0);
+            r1 = node(mid, hi, budget - 1, self1, forks, &b1, &d1);
+        }
+        GpuInner& g = inner[self];
+        std::memset(&g, 0, sizeof g);
+        set_box(g.c0, g.h0, b0);
+        set_box(g.c1, g.h1, b1);
+        for (int a = 0; a < 3; ++a) {
+            box->lo[a] = std::min(b0.lo[a], b1.lo[a]);
+            box->hi[a] = std::max(b0.hi[a], b1.hi[a]);
+        }
+        g.ref0 = r0;
+        g.ref1 = r1;
+        *depth = 1 + std::max(d0, d1);
+        return self;
     }
-    uint32_t mid;
-    if (best_axis < 0) {
-        // coincident centres, or no eligible SAH split: halve at the median of the widest axis
-        mid = (lo + hi) / 2;
-        int wa = 0;
-        for (int a = 1; a < 3; ++a)
-            if (cmax[a] - cmin[a] > cmax[wa] - cmin[wa]) wa = a;
-        if (cmax[wa] - cmin[wa] > 0.0)
-            std::nth_element(p.begin() + lo, p.begin() + mid, p.begin() + hi, [wa](const PrimBox& x, const PrimBox& y) {
-                return x.c[wa] < y.c[wa] || (x.c[wa] == y.c[wa] && x.id < y.id);
+
+    // Binned surface-area split of p[lo, hi) (reorders the range); returns the first index of the right side.
+    uint32_t split(uint32_t lo, uint32_t hi, uint32_t budget) {
+        const uint64_t cap = budget - 1 >= 32 ? (1ull << 32) : (1ull << (budget - 1));   // budget >= 1 here
+        double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], p[i].c[a]); cmax[a] = std::max(cmax[a], p[i].c[a]); }
+        // All three axes binned in one pass over the range.  Most nodes hold a handful of primitives, so
+        // the work per node is kept proportional to the bins actually occupied: a bin's box is set by its
+        // first primitive (no initialisation pass), and the sweeps below skip empty bins -- a candidate
+        // whose own bin is empty splits the set exactly like the candidate before it (same cost, and only a
+        // strictly lower cost is taken), so leaving it out changes nothing.
+        Box3 bb[3][NB];
+        uint32_t cnt[3][NB] = {};
+        double sc[3];
+        for (int a = 0; a < 3; ++a) {
+            const double ext = cmax[a] - cmin[a];
+            sc[a] = ext > 0.0 ? NB / ext : 0.0;
+        }
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                if (!(sc[a] > 0.0)) continue;
+                const int k = std::min(NB - 1, (int)((p[i].c[a] - cmin[a]) * sc[a]));
+                if (cnt[a][k]++ == 0) bb[a][k] = p[i].b;
+                else grow(bb[a][k], p[i].b);
+            }
+        int best_axis = -1, best_bin = 0;
+        double best_cost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            if (!(sc[a] > 0.0)) continue;
+            double ra[NB + 1];     // ra[k], rn[k]: half area and count of bins k.. (0 / 0 when empty)
+            uint32_t rn[NB + 1];
+            ra[NB] = 0.0;
+            rn[NB] = 0;
+            Box3 acc = empty_box();
+            for (int k = NB - 1; k > 0; --k) {
+                if (cnt[a][k]) {
+                    grow(acc, bb[a][k]);
+                    rn[k] = rn[k + 1] + cnt[a][k];
+                    ra[k] = half_area(acc);
+                } else {
+                    rn[k] = rn[k + 1];
+                    ra[k] = ra[k + 1];
+                }
+            }
+            acc = empty_box();
+            uint32_t n = 0;
+            for (int k = 0; k < NB - 1; ++k) {
+                if (!cnt[a][k]) continue;
+                grow(acc, bb[a][k]);
+                n += cnt[a][k];
+                if (rn[k + 1] == 0) break;               // nothing to the right of here any more
+                if (n > cap || rn[k + 1] > cap) continue;
+                const double cost = half_area(acc) * n + ra[k + 1] * rn[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) {
+            // coincident centres, or no eligible SAH split: halve at the median of the widest axis
+            mid = (lo + hi) / 2;
+            int wa = 0;
+            for (int a = 1; a < 3; ++a)
+                if (cmax[a] - cmin[a] > cmax[wa] - cmin[wa]) wa = a;
+            if (cmax[wa] - cmin[wa] > 0.0)
+                std::nth_element(p.begin() + lo, p.begin() + mid, p.begin() + hi, [wa](const PrimBox& x, const PrimBox& y) {
+                    return x.c[wa] < y.c[wa] || (x.c[wa] == y.c[wa] && x.id < y.id);
+                });
+        } else {
+            const double s = sc[best_axis], c0 = cmin[best_axis];
+            auto it = std::partition(p.begin() + lo, p.begin() + hi, [&](const PrimBox& q) {
+                return std::min(NB - 1, (int)((q.c[best_axis] - c0) * s)) <= best_bin;
             });
-    } else {
-        const double ext = cmax[best_axis] - cmin[best_axis], sc = NB / ext;
-        auto it = std::partition(p.begin() + lo, p.begin() + hi, [&](const PrimBox& q) {
-            return std::min(NB - 1, (int)((q.c[best_axis] - cmin[best_axis]) * sc)) <= best_bin;
-        });
-        mid = (uint32_t)(it - p.begin());
-        if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+            mid = (uint32_t)(it - p.begin());
+            if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+        }
+        return mid;
     }
-    const uint32_t self = (uint32_t)out.inner.size();
-    out.inner.emplace_back();
-    Box3 b0{}, b1{};
-    uint32_t d0 = 0, d1 = 0;
-    const uint32_t r0 = build_sah(p, lo, mid, budget - 1, out, &b0, &d0);
-    const uint32_t r1 = build_sah(p, mid, hi, budget - 1, out, &b1, &d1);
-    GpuInner& g = out.inner[self];
-    std::memset(&g, 0, sizeof g);
-    set_box(g.c0, g.h0, b0);
-    set_box(g.c1, g.h1, b1);
-    for (int a = 0; a < 3; ++a) {
-        box->lo[a] = std::min(b0.lo[a], b1.lo[a]);
-        box->hi[a] = std::max(b0.hi[a], b1.hi[a]);
+};
+
+// Threads an upload may use: the CPUs this process may run on, at most 16 (SDFGPU_BUILD_THREADS overrides).
+unsigned build_threads() {
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)CPU_COUNT(&set));
+    if (const char* e = std::getenv("SDFGPU_BUILD_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+    return std::max(1u, std::min(hw, 16u));
+}
+int build_forks() {   // levels of the hierarchy whose two sides get a thread each
+    const unsigned hw = build_threads();
+    int f = 0;
+    while ((2u << f) <= hw) ++f;
+    return f;
+}
+
+// f(lo, hi) over [0, n) in contiguous chunks, one per thread; chunks a thread could not be started for
+// run on the calling thread.  f must only write what its own indices own.
+template <class F>
+void parallel_for(uint32_t n, uint32_t grain, const F& f) {
+    const uint32_t nt = std::min<uint32_t>(build_threads(), std::max(1u, n / std::max(1u, grain)));
+    if (nt <= 1) { f(0u, n); return; }
+    const uint32_t chunk = (n + nt - 1) / nt;
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    uint32_t next = chunk;   // chunk 0 is the caller's
+    try {
+        for (; next < n; next += chunk) {
+            const uint32_t lo = next, hi = std::min(n, next + chunk);
+            th.emplace_back([&f, lo, hi] { f(lo, hi); });
+        }
+    } catch (const std::system_error&) {
     }
-    g.ref0 = r0;
-    g.ref1 = r1;
-    *depth = 1 + std::max(d0, d1);
-    return self;
+    f(0u, std::min(n, chunk));
+    for (; next < n; next += chunk) f(next, std::min(n, next + chunk));   // not started: done here
+    for (std::thread& t : th) t.join();
 }
 
 int fail(std::string* err, int code, const char* fmt, uint32_t a = 0, uint32_t b = 0) {
@@ -353,6 +447,21 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         if (dt[i].level >= 255)
             return fail(err, SDFGPU_ERR_TOO_DEEP, "node %u at level %u (the reference stack holds 256 frames)", i, dt[i].level);
     }
+    // The arithmetic on every node's matrix (finiteness here; rigidity and the Lipschitz constant of the live
+    // leaves after the structural pass, which decides what is live) runs on all threads; the structural pass
+    // itself is sequential, and reports the non-finite matrix with the lowest index at that index's turn, so
+    // the first error found is the same as in one pass.
+    std::atomic<uint32_t> first_non_finite{UINT32_MAX};
+    parallel_for(n, 8192, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i)
+            if (!finite16(dt[i].bounding_box.trans_inverse.m)) {
+                uint32_t seen = first_non_finite.load();
+                while (i < seen && !first_non_finite.compare_exchange_weak(seen, i)) {
+                }
+                return;   // later nodes of this chunk have higher indices
+            }
+    });
+    const uint32_t non_finite_at = first_non_finite.load();
     for (uint32_t i = 0; i < n; ++i) {
         const SdfOperationBlock& b = dt[i];
         if (b.is_primitive > 1 || b.parent_is_union > 1) return fail(err, SDFGPU_ERR_BAD_TREE, "node %u: bool field is not 0/1", i);
@@ -366,7 +475,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         c.dead[i] = dead ? 1 : 0;
         if (!dead) max_level_live = std::max(max_level_live, b.level);
         const float* ti = b.bounding_box.trans_inverse.m;
-        if (!finite16(ti)) return fail(err, SDFGPU_ERR_NON_FINITE, "node %u: non-finite trans_inverse", i);
+        if (i == non_finite_at) return fail(err, SDFGPU_ERR_NON_FINITE, "node %u: non-finite trans_inverse", i);
         if (b.is_primitive) {
             if (b.len != 0) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u has len %u", i, b.len);
             if (b.op_code == SDF_PRIM_SPHERE) {
@@ -389,9 +498,6 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             } else {
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported primitive op code: %u (node %u)", b.op_code, i);
             }
-            if (!dead && !bottom_row_exact(ti)) exact_rows = false;
-            if (!dead && !rigid3(ti, RIGID_TOL)) rigid = false;
-            if (!dead) lip = std::max(lip, lipschitz3(ti));
             c.prim_id[i] = n_prims++;
         } else {
             if (b.op_code != SDF_OP_UNION && b.op_code != SDF_OP_CAA_CLONE)
@@ -414,6 +520,31 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             if (b.op_code == SDF_OP_CAA_CLONE && cnt != 1)
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP,
                             "clone node %u has %u slots; the crate builds exactly one (elements.rs:222)", i, cnt);
+        }
+    }
+    {
+        // live leaves: affine rows, rigidity, Lipschitz constant (and / max reductions: order-independent)
+        const uint32_t slots = build_threads() + 1;
+        std::vector<uint8_t> not_exact(slots, 0), not_rigid(slots, 0);
+        std::vector<double> lips(slots, 1.0);
+        std::atomic<uint32_t> slot{0};
+        parallel_for(n, 8192, [&](uint32_t lo, uint32_t hi) {
+            uint8_t ne = 0, nr = 0;
+            double l = 1.0;
+            for (uint32_t i = lo; i < hi; ++i) {
+                if (!dt[i].is_primitive || c.dead[i]) continue;
+                const float* ti = dt[i].bounding_box.trans_inverse.m;
+                if (!bottom_row_exact(ti)) ne = 1;
+                if (!rigid3(ti, RIGID_TOL)) nr = 1;
+                l = std::max(l, lipschitz3(ti));
+            }
+            const uint32_t k = slot.fetch_add(1) % slots;
+            not_exact[k] = ne; not_rigid[k] = nr; lips[k] = l;
+        });
+        for (uint32_t k = 0; k < slots; ++k) {
+            if (not_exact[k]) exact_rows = false;
+            if (not_rigid[k]) rigid = false;
+            lip = std::max(lip, lips[k]);
         }
     }
     // live primitives below every node (children follow their parent in pre-order)
@@ -549,39 +680,61 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
 
     // ---- leaves, in primitive-id order ----
     out->leaves.resize(n_prims);
-    double extent_sum = 0.0;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (!dt[i].is_primitive) continue;
-        GpuLeaf& L = out->leaves[c.prim_id[i]];
-        std::memset(&L, 0, sizeof L);
-        const float* m = dt[i].bounding_box.trans_inverse.m;
-        for (int r = 0; r < 3; ++r)
-            for (int col = 0; col < 4; ++col) L.m[4 * r + col] = m[4 * col + r];
-        margin_T = std::max(margin_T, std::fabs(m[12]) + std::fabs(m[13]) + std::fabs(m[14]));
-        L.kind = dt[i].op_code;
-        if (L.kind == SDF_PRIM_SPHERE) {
-            L.param[0] = dt[i].op_specific.floats[0];
-        } else {
-            for (int a = 0; a < 3; ++a) L.param[a] = dt[i].op_specific.vec4s[0].v[a];
-        }
-        extent_sum += std::max({std::fabs((double)L.param[0]), std::fabs((double)L.param[1]), std::fabs((double)L.param[2])});
+    {
+        // per-chunk maxima of |translation| (max is order-independent, so the result does not depend on the chunking)
+        std::vector<float> chunk_T(build_threads() + 1, 0.f);
+        std::atomic<uint32_t> slot{0};
+        parallel_for(n, 8192, [&](uint32_t lo, uint32_t hi) {
+            float mt = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) {
+                if (!dt[i].is_primitive) continue;
+                GpuLeaf& L = out->leaves[c.prim_id[i]];
+                std::memset(&L, 0, sizeof L);
+                const float* m = dt[i].bounding_box.trans_inverse.m;
+                for (int r = 0; r < 3; ++r)
+                    for (int col = 0; col < 4; ++col) L.m[4 * r + col] = m[4 * col + r];
+                mt = std::max(mt, std::fabs(m[12]) + std::fabs(m[13]) + std::fabs(m[14]));
+                L.kind = dt[i].op_code;
+                if (L.kind == SDF_PRIM_SPHERE) {
+                    L.param[0] = dt[i].op_specific.floats[0];
+                } else {
+                    for (int a = 0; a < 3; ++a) L.param[a] = dt[i].op_specific.vec4s[0].v[a];
+                }
+            }
+            chunk_T[slot.fetch_add(1) % chunk_T.size()] = mt;
+        });
+        for (float v : chunk_T) margin_T = std::max(margin_T, v);
     }
+    double extent_sum = 0.0;   // summed in primitive order: the same value whatever the thread count
+    for (const GpuLeaf& L : out->leaves)
+        extent_sum += std::max({std::fabs((double)L.param[0]), std::fabs((double)L.param[1]), std::fabs((double)L.param[2])});
     out->mean_extent = n_prims ? (float)(extent_sum / n_prims) : 0.f;
     if (mode == SDFGPU_BOUNDS_OBB) out->inner_obb.reserve(n_inner);
     else out->inner.reserve(n_inner);
     Box3 root{};
     uint32_t depth = 0;
     if (mode == SDFGPU_BOUNDS_BVH) {
-        std::vector<PrimBox> prims;
-        prims.reserve(n_prims);
-        for (uint32_t i = 0; i < n; ++i) {
-            if (!dt[i].is_primitive || c.dead[i]) continue;
-            prims.emplace_back();
-            PrimBox& q = prims.back();
-            q.id = c.prim_id[i];
-            if (!leaf_aabb(dt[i], &q.b)) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u: singular transform", i);
-            for (int a = 0; a < 3; ++a) q.c[a] = 0.5 * (q.b.lo[a] + q.b.hi[a]);
-        }
+        std::vector<uint32_t> live_nodes;   // buffer index of every live primitive, in pre-order
+        live_nodes.reserve(n_prims);
+        for (uint32_t i = 0; i < n; ++i)
+            if (dt[i].is_primitive && !c.dead[i]) live_nodes.push_back(i);
+        std::vector<PrimBox> prims(live_nodes.size());
+        std::atomic<uint32_t> singular{UINT32_MAX};   // lowest buffer index whose transform cannot be inverted
+        parallel_for((uint32_t)live_nodes.size(), 4096, [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t j = lo; j < hi; ++j) {
+                const uint32_t i = live_nodes[j];
+                PrimBox& q = prims[j];
+                q.id = c.prim_id[i];
+                if (!leaf_aabb(dt[i], &q.b)) {
+                    uint32_t seen = singular.load();
+                    while (i < seen && !singular.compare_exchange_weak(seen, i)) {
+                    }
+                    continue;
+                }
+                for (int a = 0; a < 3; ++a) q.c[a] = 0.5 * (q.b.lo[a] + q.b.hi[a]);
+            }
+        });
+        if (singular.load() != UINT32_MAX) return fail(err, SDFGPU_ERR_BAD_TREE, "primitive %u: singular transform", singular.load());
         // depth budget: balanced depth + slack, never beyond the 64-entry wave stack
         const uint32_t n_live = (uint32_t)prims.size();
         uint32_t lg = 0;
@@ -589,7 +742,9 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         uint32_t slack = 8;
         if (const char* e = std::getenv("SDFGPU_BVH_SLACK")) slack = (uint32_t)std::max(0, std::atoi(e));
         const uint32_t budget = std::min(64u, std::max(1u, lg + slack));
-        out->root_ref = n_live ? build_sah(prims, 0, n_live, budget, *out, &root, &depth) : REF_NONE;
+        out->inner.resize(n_live ? n_live - 1 : 0);
+        SahBuild sah{prims, out->inner.data()};
+        out->root_ref = n_live ? sah.node(0, n_live, budget, 0, build_forks(), &root, &depth) : REF_NONE;
         if (depth > budget) return fail(err, SDFGPU_ERR_TOO_DEEP, "built hierarchy is %u levels deep (budget %u)", depth, budget);
     } else {
         out->root_ref = emit(c, 0, &root, &depth);
@@ -626,11 +781,15 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     // scene box (query reordering uses it in every mode; exact only for rigid leaves)
     {
         Box3 sb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
-        for (uint32_t i = 0; i < n; ++i) {
-            if (!dt[i].is_primitive || c.dead[i]) continue;
-            Box3 lb{};
-            if (!leaf_aabb(dt[i], &lb)) continue;
-            for (int a = 0; a < 3; ++a) { sb.lo[a] = std::min(sb.lo[a], lb.lo[a]); sb.hi[a] = std::max(sb.hi[a], lb.hi[a]); }
+        if (mode == SDFGPU_BOUNDS_BVH && out->root_ref != REF_NONE) {
+            sb = root;   // the hierarchy's root box IS the union of the live primitives' boxes
+        } else {
+            for (uint32_t i = 0; i < n; ++i) {
+                if (!dt[i].is_primitive || c.dead[i]) continue;
+                Box3 lb{};
+                if (!leaf_aabb(dt[i], &lb)) continue;
+                for (int a = 0; a < 3; ++a) { sb.lo[a] = std::min(sb.lo[a], lb.lo[a]); sb.hi[a] = std::max(sb.hi[a], lb.hi[a]); }
+            }
         }
         for (int a = 0; a < 3; ++a) {
             info.scene_lo[a] = std::isfinite(sb.lo[a]) ? (float)sb.lo[a] : 0.f;
