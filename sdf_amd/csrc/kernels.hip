@@ -26,6 +26,27 @@ namespace sdfgpu {
 
 // ------------------------------------------------------------ primitives --
 
+// Correctly rounded square root for the hot paths.  The compiler expands sqrtf for this target into
+// v_sqrt_f32 (1 ulp) + a one-step correction from the two residuals x - s * (s -/+ 1 ulp), wrapped in a
+// 2^32 pre-scale for x < 2^-96 (where a residual would lose bits) and a class test for +-0 / +inf:
+// 17 instructions, more than the primitive formula around it.  The arguments here are squared
+// distances, ordinary numbers unless a point sits exactly on a primitive's centre or inside a box:
+// a wavefront whose arguments all lie in [2^-96, +inf) runs the same correction without the wrapper
+// (the wrapper is the identity there, so the bits are the compiler's), any other wavefront runs the
+// compiler's expansion.  The choice is per wavefront (one ballot), so there is no divergence.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const bool ordinary = (u - 0x0F800000u) < 0x70000000u;   // 2^-96 <= x < +inf (and x > 0)
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return __builtin_sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float ed = __builtin_fmaf(-sd, s, x), eu = __builtin_fmaf(-su, s, x);
+    float r = ed <= 0.f ? sd : s;
+    r = eu > 0.f ? su : r;
+    return r;
+}
+
 // World point -> primitive frame: rows of trans_inverse, glam Mat4*Vec4 order
 // ((c0*x + c1*y) + c2*z) + c3*w with w = 1 (c3*1 is exact).  faux_shader.rs:165.
 __device__ __forceinline__ void leaf_point(const float* __restrict__ m, float px, float py, float pz,
@@ -41,11 +62,11 @@ __device__ __forceinline__ void leaf_point(const float* __restrict__ m, float px
 __device__ __forceinline__ float prim_value(uint32_t kind, float p0, float p1, float p2, float lx, float ly,
                                             float lz) {
     if (kind == SDF_PRIM_SPHERE) {
-        return __builtin_sqrtf((lx * lx + ly * ly) + lz * lz) - p0;
+        return sqrt_rn((lx * lx + ly * ly) + lz * lz) - p0;
     }
     float qx = __builtin_fabsf(lx) - p0, qy = __builtin_fabsf(ly) - p1, qz = __builtin_fabsf(lz) - p2;
     float mx = qx > 0.f ? qx : 0.f, my = qy > 0.f ? qy : 0.f, mz = qz > 0.f ? qz : 0.f;
-    float l = __builtin_sqrtf((mx * mx + my * my) + mz * mz);
+    float l = sqrt_rn((mx * mx + my * my) + mz * mz);
     return l + __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
 }
 
@@ -61,7 +82,7 @@ __device__ __forceinline__ float prim_value_lane(uint32_t kind, float p0, float 
     const float ab = (mx * mx + my * my) + mz * mz;
     const float as = (lx * lx + ly * ly) + lz * lz;
     const bool sph = kind == SDF_PRIM_SPHERE;
-    const float r = __builtin_sqrtf(sph ? as : ab);
+    const float r = sqrt_rn(sph ? as : ab);
     const float in = __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
     return sph ? r - p0 : r + in;
 }
