@@ -197,10 +197,10 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
         "ms_per_step": el / a.knn_steps * 1e3, "steps": a.knn_steps,
         "config": {"workload": wl.name, "n_points": n_total, "k": k, "n_prims": wl.n_prims, "seed": hex(wl.seed),
                    "tree_levels": int(info.max_level), "tree_bytes_hbm": int(info.device_bytes),
-                   "points": "uniform in 1.2x the scene cube, unsorted (Morton-reordered inside the call)",
+                   "points": "uniform in 1.2x the scene cube, unsorted (reordered along the Hilbert curve inside the call)",
                    "partition": "contiguous query slices, results sharded"},
     }
-    # the same batch handed over already Morton-sorted by the caller -- with the library's own
+    # the same batch handed over already sorted along a space-filling curve by the caller -- with the library's own
     # reordering still on (it sorts a sorted batch) and with it off (the walk alone: no permutation traffic)
     pts_sorted = torch.from_numpy(W.query_points(wl, n_total, morton=True)[lo:hi]).to(dev)
     step_s = lambda: gpu.knn_dev(pts_sorted.data_ptr(), n, k, d_out.data_ptr(), i_out.data_ptr(), stream)  # noqa: E731
@@ -210,7 +210,7 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
     e_off, e1_off = timed(step_s), timed(step1_s)
     gpu.set_reorder(True)
     out["presorted"] = {
-        "points": "the same points, Morton-sorted by the caller before the call",
+        "points": "the same points, sorted along the Hilbert curve by the caller before the call (workloads.hilbert_keys)",
         "k8_reorder_on": {"value": n_total * a.knn_steps / e_on, "ms_per_step": e_on / a.knn_steps * 1e3},
         "k8_reorder_off": {"value": n_total * a.knn_steps / e_off, "ms_per_step": e_off / a.knn_steps * 1e3},
         "k1_reorder_on": {"value": n_total * a.knn_steps / e1_on, "ms_per_step": e1_on / a.knn_steps * 1e3},
@@ -232,7 +232,7 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
         call_ms = float(np.mean(kms))
         tr, trn = profiled_traffic("knn_kernel<1, 8")
         out["roofline"] = roofline_object(st, call_ms, "sdfgpu::knn_kernel<1, 8, false>", n * 16 + n * k * 8 + int(info.device_bytes),
-                                          note="kernel_ms_avg = the whole sdfgpu_knn_dev call (Morton keys + radix sort + walk) under HIP "
+                                          note="kernel_ms_avg = the whole sdfgpu_knn_dev call (curve keys + radix sort + walk) under HIP "
                                                "events, so the kernel's own rate is higher (profiles/ has its rocprofv3 duration); fp32 "
                                                "VALU-bound walk, K-slot insertion counted as 2 flops per offered primitive",
                                           traffic=tr, traffic_note=trn)

@@ -49,30 +49,64 @@ def march(wl: Workload):
     return march_params(max_steps=128, eps_hit=1e-3, t_min=0.0, t_max=6.0 * L, normal_h=1e-4)
 
 
-def query_points(wl: Workload, n=None, morton=False):
-    """n points ~ U[-1.2 L, 1.2 L)^3, w = 1, from a seeded numpy generator."""
+def query_points(wl: Workload, n=None, morton=False, curve="hilbert"):
+    """n points ~ U[-1.2 L, 1.2 L)^3, w = 1, from a seeded numpy generator.  morton=True: sorted along a
+    space-filling curve by the caller (`curve`: "hilbert", the order the library itself uses, or "morton")."""
     n = n or wl.n_points
     L = default_extent(wl.n_prims)
     rng = np.random.default_rng(wl.seed)
     p = np.ones((n, 4), np.float32)
     p[:, :3] = rng.uniform(-1.2 * L, 1.2 * L, (n, 3)).astype(np.float32)
     if morton:
-        p = p[np.argsort(morton_keys(p[:, :3], L * 1.2), kind="stable")]
+        keys = hilbert_keys(p[:, :3], L * 1.2) if curve == "hilbert" else morton_keys(p[:, :3], L * 1.2)
+        p = p[np.argsort(keys, kind="stable")]
     return p
+
+
+def _cells(xyz, half_extent):
+    return np.clip(((xyz / half_extent) * 0.5 + 0.5) * 1024.0, 0, 1023).astype(np.uint64)
+
+
+def _spread10(v):
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    v = (v | (v << 2)) & 0x09249249
+    return v
 
 
 def morton_keys(xyz, half_extent):
     """30-bit Morton code of points in [-half_extent, half_extent)^3."""
-    q = np.clip(((xyz / half_extent) * 0.5 + 0.5) * 1024.0, 0, 1023).astype(np.uint64)
+    q = _cells(xyz, half_extent)
+    return (_spread10(q[:, 0]) | (_spread10(q[:, 1]) << 1) | (_spread10(q[:, 2]) << 2)).astype(np.uint32)
 
-    def spread(v):
-        v = (v | (v << 16)) & 0x030000FF
-        v = (v | (v << 8)) & 0x0300F00F
-        v = (v | (v << 4)) & 0x030C30C3
-        v = (v | (v << 2)) & 0x09249249
-        return v
 
-    return (spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)).astype(np.uint32)
+def hilbert_keys(xyz, half_extent):
+    """30-bit Hilbert index of the same cells (Skilling 2004, axes -> transposed index; the arithmetic
+    of sort.hip's key kernel, vectorised)."""
+    q = _cells(xyz, half_extent)
+    X = [q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy()]
+    Q = 1 << 9
+    while Q > 1:
+        P = Q - 1
+        for a in range(3):
+            hit = (X[a] & Q) != 0
+            t = (X[0] ^ X[a]) & P
+            X0 = np.where(hit, X[0] ^ P, X[0] ^ t)
+            if a:
+                X[a] = np.where(hit, X[a], X[a] ^ t)
+            X[0] = X0
+        Q >>= 1
+    X[1] ^= X[0]
+    X[2] ^= X[1]
+    t = np.zeros_like(X[0])
+    Q = 1 << 9
+    while Q > 1:
+        t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    for a in range(3):
+        X[a] ^= t
+    return ((_spread10(X[0]) << 2) | (_spread10(X[1]) << 1) | _spread10(X[2])).astype(np.uint32)
 
 
 # Algorithmic fp32 operations per unit of work of the AABB-mode kernels
