@@ -674,15 +674,19 @@ struct AccK {
     __device__ __forceinline__ float radius() const { return dist(K - 1); }
     __device__ __forceinline__ void skipped(float) {}
     __device__ __forceinline__ void offer(float nd, uint32_t nid) {
-        unsigned long long cur = ((unsigned long long)ord_f32(nd) << 32) | (unsigned long long)(0xFFFFFFFEu - nid);
+        const unsigned long long cur = ((unsigned long long)ord_f32(nd) << 32) | (unsigned long long)(0xFFFFFFFEu - nid);
         if (!(cur < key[K - 1])) return;
+        // The keys are sorted, so the K comparisons against the NEW key are monotone (false ... false,
+        // true ... true) and independent of one another: slot j takes its left neighbour's old key when the
+        // new one sorts before that neighbour, the new key when it sorts between them, and keeps its own
+        // otherwise.  K compares + 2 selects per slot, no chain from slot to slot (a compare-exchange
+        // ladder is 2 compares + 2 selects per slot, each waiting for the slot before it).
+        bool lt[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const bool lt = cur < key[j];
-            const unsigned long long lo = lt ? cur : key[j];
-            cur = lt ? key[j] : cur;
-            key[j] = lo;
-        }
+        for (int j = 0; j < K; ++j) lt[j] = cur < key[j];
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) key[j] = lt[j - 1] ? key[j - 1] : (lt[j] ? cur : key[j]);
+        key[0] = lt[0] ? cur : key[0];
     }
 };
 
