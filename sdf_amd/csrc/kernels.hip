@@ -379,7 +379,8 @@ pop:
 // Contract of the block: on entry `cur` is an internal/leaf reference or
 // REF_POP ("take the next pending subtree"); on exit `cur` is a leaf reference
 // to evaluate, with that leaf's record in `rec`, or REF_NONE when the walk is
-// over.  s[80:95] hold the internal node's record, s96/s97 take the prefetches.  Hazards: no VALU-written SGPR is read by a VALU here (gfx950 needs
+// over.  s[48:63] hold the internal node's record (and, on exit, the leaf's: the same registers, so the block costs
+// 18 fixed SGPRs, placed low so that they do not raise the kernel's SGPR count), s64/s65 take the prefetches.  Hazards: no VALU-written SGPR is read by a VALU here (gfx950 needs
 // two wait states for that); lane masks go VALU->SALU->VALU, which interlocks.
 constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 
@@ -390,25 +391,25 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_bitcmp1_b32 %[cur], 31\n\t"                                                                     \
     "s_cbranch_scc1 .Ldone%=\n\t"                                                                      \
     "s_lshl_b32 %[t0], %[cur], 6\n\t"                                                                  \
-    "s_load_dwordx16 s[80:95], %[base], %[t0]\n\t"                                                     \
+    "s_load_dwordx16 s[48:63], %[base], %[t0]\n\t"                                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
     CNT_INNER                                                                                          \
     PREFETCH                                                                                           \
-    "v_subrev_f32 %[a], s80, %[px]\n\t"                                                              \
-    "v_subrev_f32 %[b], s81, %[py]\n\t"                                                              \
-    "v_subrev_f32 %[c], s82, %[pz]\n\t"                                                              \
-    "v_sub_f32 %[a], |%[a]|, s83 clamp\n\t"                                                          \
-    "v_sub_f32 %[b], |%[b]|, s84 clamp\n\t"                                                          \
-    "v_sub_f32 %[c], |%[c]|, s85 clamp\n\t"                                                          \
+    "v_subrev_f32 %[a], s48, %[px]\n\t"                                                              \
+    "v_subrev_f32 %[b], s49, %[py]\n\t"                                                              \
+    "v_subrev_f32 %[c], s50, %[pz]\n\t"                                                              \
+    "v_sub_f32 %[a], |%[a]|, s51 clamp\n\t"                                                          \
+    "v_sub_f32 %[b], |%[b]|, s52 clamp\n\t"                                                          \
+    "v_sub_f32 %[c], |%[c]|, s53 clamp\n\t"                                                          \
     "v_mul_f32 %[k0], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k0], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k0], %[c], %[c]\n\t"                                                               \
-    "v_subrev_f32 %[a], s86, %[px]\n\t"                                                              \
-    "v_subrev_f32 %[b], s87, %[py]\n\t"                                                              \
-    "v_subrev_f32 %[c], s88, %[pz]\n\t"                                                              \
-    "v_sub_f32 %[a], |%[a]|, s89 clamp\n\t"                                                          \
-    "v_sub_f32 %[b], |%[b]|, s90 clamp\n\t"                                                          \
-    "v_sub_f32 %[c], |%[c]|, s91 clamp\n\t"                                                          \
+    "v_subrev_f32 %[a], s54, %[px]\n\t"                                                              \
+    "v_subrev_f32 %[b], s55, %[py]\n\t"                                                              \
+    "v_subrev_f32 %[c], s56, %[pz]\n\t"                                                              \
+    "v_sub_f32 %[a], |%[a]|, s57 clamp\n\t"                                                          \
+    "v_sub_f32 %[b], |%[b]|, s58 clamp\n\t"                                                          \
+    "v_sub_f32 %[c], |%[c]|, s59 clamp\n\t"                                                          \
     "v_mul_f32 %[k1], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k1], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k1], %[c], %[c]\n\t"                                                               \
@@ -431,8 +432,8 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "v_cndmask_b32 %[a], %[k0], %[k1], vcc\n\t"   /* key of the deferred child */                      \
     "v_lshl_add_u32 %[b], %[sp], 8, %[sa]\n\t"                                                         \
     "ds_write_b32 %[b], %[a]\n\t"                                                                      \
-    "s_cselect_b32 %[t1], s93, s92\n\t"      /* deferred reference */                                  \
-    "s_cselect_b32 %[cur], s92, s93\n\t"                                                               \
+    "s_cselect_b32 %[t1], s61, s60\n\t"      /* deferred reference */                                  \
+    "s_cselect_b32 %[cur], s60, s61\n\t"                                                               \
     "s_mov_b32 m0, %[sp]\n\t"                                                                          \
     "s_nop 0\n\t"                                                                                      \
     "v_writelane_b32 %[refs], %[t1], m0\n\t"                                                           \
@@ -440,13 +441,13 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_branch .Ltop%=\n"                                                                               \
     ".Lonly0%=:\n\t"                                                                                   \
     LBMIN_K1                                                                                           \
-    "s_mov_b32 %[cur], s92\n\t"                                                                        \
+    "s_mov_b32 %[cur], s60\n\t"                                                                        \
     "s_branch .Ltop%=\n"                                                                               \
     ".Lno0%=:\n\t"                                                                                     \
     LBMIN_K0                                                                                           \
     "s_and_b64 %[mk1], vcc, %[drive]\n\t"                                                               \
     "s_cbranch_scc0 .Lnone%=\n\t"                                                                      \
-    "s_mov_b32 %[cur], s93\n\t"                                                                        \
+    "s_mov_b32 %[cur], s61\n\t"                                                                        \
     "s_branch .Ltop%=\n"                                                                               \
     ".Lnone%=:\n\t"                                                                                    \
     LBMIN_K1                                                                                           \
@@ -484,14 +485,14 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 #define SDFGPU_WALK_PREFETCH ""
 #else
 #define SDFGPU_WALK_PREFETCH                                                                           \
-    "s_lshl_b32 %[t0], s92, 6\n\t"                                                                     \
-    "s_bitcmp1_b32 s92, 31\n\t"                                                                        \
+    "s_lshl_b32 %[t0], s60, 6\n\t"                                                                     \
+    "s_bitcmp1_b32 s60, 31\n\t"                                                                        \
     "s_cselect_b64 %[t], %[lbase], %[base]\n\t"                                                        \
-    "s_load_dword s96, %[t], %[t0]\n\t"                                                                \
-    "s_lshl_b32 %[t1], s93, 6\n\t"                                                                     \
-    "s_bitcmp1_b32 s93, 31\n\t"                                                                        \
+    "s_load_dword s64, %[t], %[t0]\n\t"                                                                \
+    "s_lshl_b32 %[t1], s61, 6\n\t"                                                                     \
+    "s_bitcmp1_b32 s61, 31\n\t"                                                                        \
     "s_cselect_b64 %[mk0], %[lbase], %[base]\n\t"                                                       \
-    "s_load_dword s97, %[mk0], %[t1]\n\t"
+    "s_load_dword s65, %[mk0], %[t1]\n\t"
 #endif
 
 // DBG: the block also counts the internal nodes and leaves it visits in two SGPRs (the instrumented
@@ -507,12 +508,11 @@ __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& r
 #define SDFGPU_WALK_OUT                                                                                               \
     [cur] "+s"(cur), [sp] "+s"(sp), [refs] "+v"(refs), [lb] "+v"(lb), [mk0] "=&s"(m0), [mk1] "=&s"(m1), [t] "=&s"(t), \
       [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [k0] "=&v"(k0),          \
-      [k1] "=&v"(k1), [rec] "=&s"(rec)
+      [k1] "=&v"(k1), [rec] "=&{s[48:63]}"(rec)
 #define SDFGPU_WALK_IN                                                                                                \
     [thr] "v"(thr), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [drive] "s"(drive), [base] "s"(base), [lbase] "s"(lbase), [sa] "v"(sa)
 #define SDFGPU_WALK_CLOBBER                                                                                           \
-    "vcc", "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",       \
-      "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+    "vcc", "scc", "memory", "s64", "s65"
 #define SDFGPU_LB_K0 "v_min_f32 %[lb], %[lb], %[k0]\n\t"
 #define SDFGPU_LB_K1 "v_min_f32 %[lb], %[lb], %[k1]\n\t"
 #define SDFGPU_LB_A "v_min_f32 %[lb], %[lb], %[a]\n\t"
