@@ -163,6 +163,7 @@ struct TreeView {
     float inv_bscale;   // 1 / bscale
     float bscale;       // AABB modes: power-of-two scale of the boxes (point and threshold are scaled to match)
     float lip;          // max change of any leaf value per unit the point moves, rounded up (1.000004 for rigid leaves)
+    uint32_t prefetch;  // 1: the walk warms the scalar cache with both children's records (trees beyond one XCD's L2)
 };
 
 // Absolute slack covering the rounding of a leaf value at point p (DESIGN.md "pruning").
@@ -480,10 +481,12 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 // record of whichever child is visited next then costs a cache hit (~100 cycles)
 // instead of an L2 round trip (~210).  The dwords land in two scratch SGPRs; the block
 // waits for every outstanding scalar load before it ends, so none can land later in a
-// register the compiler has meanwhile given to something else.
-#ifdef SDFGPU_NO_PREFETCH
-#define SDFGPU_WALK_PREFETCH ""
-#else
+// register the compiler has meanwhile given to something else.  It costs 8 scalar
+// instructions per node, which only pays when records actually miss: measured at 8 waves
+// per SIMD, the 100k-primitive tree (12.8 MB) is 5 % faster with it (kNN 1.14 vs 1.20 ms),
+// the 10k-primitive tree (1.3 MB, resident in every XCD's L2) 2.4 % slower (frame 1.83 vs
+// 1.78 ms) -- so TreeView::prefetch selects, per tree (make_view), between two copies of the walk (a
+// test-and-skip inside the block costs a taken branch per node and gave the 2.4 % back).
 #define SDFGPU_WALK_PREFETCH                                                                           \
     "s_lshl_b32 %[t0], s60, 6\n\t"                                                                     \
     "s_bitcmp1_b32 s60, 31\n\t"                                                                        \
@@ -493,11 +496,10 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "s_bitcmp1_b32 s61, 31\n\t"                                                                        \
     "s_cselect_b64 %[mk0], %[lbase], %[base]\n\t"                                                       \
     "s_load_dword s65, %[mk0], %[t1]\n\t"
-#endif
 
 // DBG: the block also counts the internal nodes and leaves it visits in two SGPRs (the instrumented
 // build behind SDFGPU_OPT_STATS_ASM_WALK; tests compare them with the C++ walk's counters).
-template <bool TRACK, bool DBG>
+template <bool TRACK, bool DBG, bool PF>
 __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& refs, float& lb, float thr, float px,
                                              float py, float pz, unsigned long long drive, const GpuInner* base,
                                              const GpuLeaf* lbase, uint32_t sa, f32x16& rec, uint32_t& n_inner,
@@ -519,22 +521,31 @@ __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& r
     // The block writes M0 (lane select of v_writelane).  M0 is a reserved register to this compiler: it
     // never keeps a value live in it across other code and re-materialises it before each use of its own,
     // so it cannot be listed as a clobber (-Winline-asm: "clobber list contains reserved registers: m0").
-    if constexpr (DBG) {
-        static_assert(!TRACK, "the counting walk is instantiated for the query kernels only");
-        asm volatile(SDFGPU_WALK_ASM("", "", "", SDFGPU_WALK_PREFETCH, "s_add_u32 %[ni], %[ni], 1\n\t", "s_add_u32 %[nl], %[nl], 1\n\t")
-                     : SDFGPU_WALK_OUT, [ni] "+s"(n_inner), [nl] "+s"(n_leaf) : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);
-    } else if constexpr (TRACK) {
-        asm volatile(SDFGPU_WALK_ASM(SDFGPU_LB_K0, SDFGPU_LB_K1, SDFGPU_LB_A, SDFGPU_WALK_PREFETCH, "", "")
-                     : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);
-    } else {
-        asm volatile(SDFGPU_WALK_ASM("", "", "", SDFGPU_WALK_PREFETCH, "", "") : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);
+    // PF selects the copy with / without the scalar-cache prefetch (string literals cannot be chosen by a
+    // template argument, hence the two branches per flavour).
+#define SDFGPU_WALK_FLAVOUR(PFTEXT)                                                                                   \
+    if constexpr (DBG) {                                                                                              \
+        static_assert(!TRACK, "the counting walk is instantiated for the query kernels only");                        \
+        asm volatile(SDFGPU_WALK_ASM("", "", "", PFTEXT, "s_add_u32 %[ni], %[ni], 1\n\t", "s_add_u32 %[nl], %[nl], 1\n\t") \
+                     : SDFGPU_WALK_OUT, [ni] "+s"(n_inner), [nl] "+s"(n_leaf) : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);   \
+    } else if constexpr (TRACK) {                                                                                     \
+        asm volatile(SDFGPU_WALK_ASM(SDFGPU_LB_K0, SDFGPU_LB_K1, SDFGPU_LB_A, PFTEXT, "", "")                         \
+                     : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);                                       \
+    } else {                                                                                                          \
+        asm volatile(SDFGPU_WALK_ASM("", "", "", PFTEXT, "", "") : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER); \
     }
+    if constexpr (PF) {
+        SDFGPU_WALK_FLAVOUR(SDFGPU_WALK_PREFETCH)
+    } else {
+        SDFGPU_WALK_FLAVOUR("")
+    }
+#undef SDFGPU_WALK_FLAVOUR
 #undef SDFGPU_WALK_OUT
 #undef SDFGPU_WALK_IN
 #undef SDFGPU_WALK_CLOBBER
 }
 
-template <int MODE, bool DBG, class Acc>
+template <int MODE, bool DBG, bool PF, class Acc>
 __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, float py, float pz,
                                                 unsigned long long drive, float ext, Acc& acc,
                                                 float* __restrict__ stk, uint32_t lane, WaveCounters& wc) {
@@ -552,7 +563,7 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
     uint32_t n_inner = 0, n_leaf = 0;   // DBG only
     for (;;) {
         f32x16 L;   // the leaf's record, fetched inside the block (undefined when the walk is over)
-        walk_advance<Acc::TRACKS, DBG>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L, n_inner, n_leaf);
+        walk_advance<Acc::TRACKS, DBG, PF>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L, n_inner, n_leaf);
         cur = __builtin_amdgcn_readfirstlane(cur);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (cur == REF_NONE) break;
@@ -576,7 +587,8 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
                                             float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
                                             WaveCounters& wc) {
     if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT == 1) nn_traverse_cxx<MODE, COUNT != 0>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else nn_traverse_asm<MODE, COUNT == 2>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else if (__builtin_amdgcn_readfirstlane(T.prefetch)) nn_traverse_asm<MODE, COUNT == 2, true>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else nn_traverse_asm<MODE, COUNT == 2, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
 }
 
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
@@ -1380,6 +1392,9 @@ static TreeView make_view(const DeviceTree& d) {
     v.lip = d.lipschitz;
     v.bscale = d.box_scale;
     v.inv_bscale = 1.0f / d.box_scale;
+    // both record arrays together beyond one XCD's 4 MB L2 (SDFGPU_PREFETCH=0/1 overrides, for measurements)
+    static const int forced = [] { const char* e = std::getenv("SDFGPU_PREFETCH"); return e ? std::atoi(e) : -1; }();
+    v.prefetch = forced >= 0 ? (uint32_t)(forced != 0) : (uint32_t)((size_t)d.n_leaf * (sizeof(GpuLeaf) + sizeof(GpuInner)) > (4u << 20));
     return v;
 }
 
