@@ -883,8 +883,12 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
     }
     for (;;) {
-        const bool active = (state == 0u) & (s < pa.step_end);      // still marching in this pass
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        // Wave masks are formed from the ballots of the individual compares: a ballot of a compare IS the
+        // compare's own mask, while a ballot of a combined flag is materialised per lane and compared again.
+        const bool a_state = state == 0u, a_steps = s < pa.step_end;
+        const bool active = a_state & a_steps;                       // still marching in this pass
+        const unsigned long long m_active = __builtin_amdgcn_ballot_w64(a_state) & __builtin_amdgcn_ballot_w64(a_steps);
+        if (m_active == 0ull) break;
         // a lane that is not marching recomputes the point it stopped at (t is no longer advanced)
         px = ox + dx * t;
         py = oy + dy * t;
@@ -897,16 +901,17 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         const float seed = prim_value_lane(__builtin_bit_cast(uint32_t, c3.w), c3.x, c3.y, c3.z, lx, ly, lz);
         float best = seeded ? seed : __builtin_inff();
         uint32_t bid = last;
-        const bool certified = active & seeded & ((best + 2.0f * mg) < budget);
+        const bool c_bound = (best + 2.0f * mg) < budget;
+        const bool certified = active & seeded & c_bound;
         if constexpr (COUNT) wc.wave_steps += 1;
         bool adv;
-        const bool cheap = __builtin_amdgcn_ballot_w64(certified) != 0ull;
+        const bool cheap = (m_active & __builtin_amdgcn_ballot_w64(seeded) & __builtin_amdgcn_ballot_w64(c_bound)) != 0ull;
         if (cheap) {
             adv = certified;   // the others hold their position
             n_cheap += 1;
         } else {
             // no marching lane can certify: one walk for all of them
-            const unsigned long long dmask = __builtin_amdgcn_ballot_w64(active);
+            const unsigned long long dmask = m_active;
             if constexpr (COUNT) wc.wave_walks += 1;
             AccTracked acc{best, bid, __builtin_inff(), __builtin_inff()};
             nn_traverse<MODE, COUNT>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
