@@ -497,6 +497,22 @@ def main():
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm = None
+            if comm is not None:
+                # one trial frame through the communicator: an error it reports (as opposed to a hang) sends
+                # every rank to the torch path instead of ending the run
+                good = 1
+                try:
+                    sl = slots[0]
+                    comm.render_frame(cam, w, h, mp, 0, *(sl.out_ptrs if rank == 0 else (0, 0, 0, 0)), sl.stream.cuda_stream)
+                    torch.cuda.synchronize()
+                except Exception as e:   # noqa: BLE001
+                    print(f"[bench rank {rank}] library communicator failed on its trial frame ({e}); using torch all-gather", file=sys.stderr)
+                    good = 0
+                ok = torch.tensor([good], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    comm.close()
+                    comm = None
         gather_kind = "RCCL grouped send/recv to rank 0 (sdfgpu_render_frame_comm)" if comm is not None else (f"{a.backend} all-gather (torch.distributed)")
 
         def step(k=0):
