@@ -474,10 +474,6 @@ def main():
         # device addresses of every plane, once (the buffers live as long as the slots)
         for sl in slots:
             sl.mine_ptrs = tuple(t.data_ptr() for t in P.planes(sl.mine, world, tiles))
-            sl.part_ptrs = []
-            for r in range(world):
-                part = P.planes(sl.gathered[r * nbytes: (r + 1) * nbytes], world, tiles)
-                sl.part_ptrs.append((P.rank_tiles(r, world, tiles), tuple(t.data_ptr() for t in part)))
             sl.out_ptrs = (sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(), sl.o_prim.data_ptr())
 
         # Assembly through the library's own communicator (sdfgpu_render_frame_comm: tile share ->
@@ -530,9 +526,9 @@ def main():
                     host = torch.empty(world * nbytes, dtype=torch.uint8)
                     dist.all_gather_into_tensor(host, sl.mine.cpu())
                     sl.gathered.copy_(host)
-                if rank == 0:
-                    for (rf, rs, rc), ptrs in sl.part_ptrs:
-                        gpu.untile_dev(w, h, rf, rs, rc, *ptrs, *sl.out_ptrs, sl.stream.cuda_stream)
+                if rank == 0:   # every rank's share in one launch (rank 0's own chunk is the first of the gathered ones)
+                    gpu.untile_gathered_dev(w, h, world, 0, sl.gathered.data_ptr(), sl.gathered.data_ptr(), *sl.out_ptrs,
+                                            sl.stream.cuda_stream)
 
     def barrier():
         if dist is not None:

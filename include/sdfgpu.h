@@ -292,6 +292,21 @@ int sdfgpu_untile_dev(sdfgpu_ctx* ctx, uint32_t width, uint32_t height,
                       uint8_t* d_hit, float* d_depth, float* d_normal_xyz,
                       uint32_t* d_prim, void* hip_stream);
 
+/* Whole-frame assembly in one launch, for a frame whose tiles were dealt round-robin over `world`
+ * ranks (rank p rendered tiles p, p + world, ... with sdfgpu_render_tiles_dev into ONE packed buffer
+ * of four planes, [depth | normal xyz | prim | hit], each plane sized for ceil(tiles / world) tiles
+ * of 64 pixels; sdfgpu_packed_share_bytes gives the buffer's size).  Rank p's buffer is read at
+ * d_gathered + p * share_bytes, except rank `self`, whose buffer is read at d_mine (pass
+ * d_gathered + self * share_bytes after an all-gather).  No counterpart in the reference (it has
+ * no multi-device code); this is the assembling rank's half of sdfgpu_render_frame_comm for hosts
+ * that bring their own collective. */
+size_t sdfgpu_packed_share_bytes(uint32_t width, uint32_t height, uint32_t world);
+int sdfgpu_untile_gathered_dev(sdfgpu_ctx* ctx, uint32_t width, uint32_t height,
+                               uint32_t world, uint32_t self,
+                               const void* d_gathered, const void* d_mine,
+                               uint8_t* d_hit, float* d_depth, float* d_normal_xyz,
+                               uint32_t* d_prim, void* hip_stream);
+
 /* ---- multi-GPU framebuffer assembly ------------------------------------- */
 /* No reference counterpart (the crate is single-threaded).  One process per GPU, each with
  * its own context and the same tree uploaded.  A communicator wraps an RCCL communicator (bound at

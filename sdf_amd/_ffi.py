@@ -158,6 +158,8 @@ GPU_SYMBOLS = {
         [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
     ),
     "sdfgpu_untile_dev": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdfgpu_packed_share_bytes": (C.c_size_t, [_u32, _u32, _u32]),
+    "sdfgpu_untile_gathered_dev": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdfgpu_comm_get_id": (_i, [_vp, _vp]),
     "sdfgpu_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "sdfgpu_comm_destroy": (None, [_vp]),

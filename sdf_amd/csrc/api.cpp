@@ -720,6 +720,27 @@ int sdfgpu_untile_dev(sdfgpu_ctx* c, uint32_t w, uint32_t h, uint32_t tile_first
     return SDFGPU_OK;
 }
 
+size_t sdfgpu_packed_share_bytes(uint32_t w, uint32_t h, uint32_t world) {
+    if (world == 0) return 0;
+    const uint64_t tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
+    return (size_t)((tiles + world - 1) / world) * 64u * 21u;   // depth 4 + normal 12 + prim 4 + hit 1 bytes per pixel
+}
+
+int sdfgpu_untile_gathered_dev(sdfgpu_ctx* c, uint32_t w, uint32_t h, uint32_t world, uint32_t self, const void* d_gathered,
+                               const void* d_mine, uint8_t* d_hit, float* d_depth, float* d_normal, uint32_t* d_prim,
+                               void* stream) {
+    if (!c) return SDFGPU_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (w == 0 || h == 0) return SDFGPU_OK;
+    if (world == 0 || self >= world) return set_err(c, SDFGPU_ERR_INVALID_ARG, "world / self out of range");
+    if ((uint64_t)w * h > (1ull << 30)) return set_err(c, SDFGPU_ERR_TOO_LARGE, "image larger than 2^30 pixels");
+    if (!d_hit || !d_mine || (world > 1 && !d_gathered)) return set_err(c, SDFGPU_ERR_INVALID_ARG, "null buffer");
+    const size_t nbytes = sdfgpu_packed_share_bytes(w, h, world);
+    HIP_TRY(c, launch_untile_gathered(w, h, world, self, nbytes / 21u, nbytes, d_gathered, d_mine, d_hit, d_depth, d_normal, d_prim,
+                                      (hipStream_t)stream));
+    return SDFGPU_OK;
+}
+
 int sdfgpu_render(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h, const sdfgpu_march_params* mp,
                   uint8_t* hit, float* depth, float* normal, uint32_t* prim) {
     int rc = check_ready(c);

@@ -236,14 +236,12 @@ int sdfgpu_render_frame_comm(sdfgpu_ctx* c, sdfgpu_comm* m, const sdfgpu_camera*
         if (e != ncclSuccess) return nccl_fail(c, e, "ncclSend / ncclRecv");
         if (e2 != ncclSuccess) return nccl_fail(c, e2, "ncclGroupEnd");
     }
-    // 3. assembly on the root: tile-compact -> row-major, one scatter per rank's share
+    // 3. assembly on the root: tile-compact -> row-major, every rank's share in one launch
     if (is_root) {
-        for (uint32_t p = 0; p < world; ++p) {
-            const Planes src = p == rank ? mine : planes_of((char*)s->gathered + (size_t)p * nbytes, px);
-            if ((rc = sdfgpu_untile_dev(c, w, h, p, world, count_of(p), src.hit, src.depth, src.normal, src.prim, d_hit, d_depth,
-                                        d_normal, d_prim, stream)))
-                return rc;
-        }
+        if (hipSetDevice(sdfgpu::ctx_device(c)) != hipSuccess) return fail(c, SDFGPU_ERR_HIP, "hipSetDevice");
+        if (sdfgpu::launch_untile_gathered(w, h, world, rank, px, nbytes, s->gathered, s->mine, d_hit, d_depth, d_normal, d_prim,
+                                           stream) != hipSuccess)
+            return fail(c, SDFGPU_ERR_HIP, "untile launch");
     }
     return SDFGPU_OK;
 }

@@ -1063,6 +1063,35 @@ __global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t he
     if (o_prim) o_prim[o] = t_prim[s];
 }
 
+// The same scatter for a whole frame whose tiles were dealt round-robin over `world` ranks, in ONE launch
+// (the assembling rank of sdfgpu_render_frame_comm: one launch per frame instead of one per rank, which
+// matters when a frame's share is a quarter of a millisecond).  Rank p's packed buffer is
+// [depth | normal | prim | hit] planes of `px` pixels at gathered + p * nbytes; the assembling rank's
+// own share is read from `mine`.
+__global__ __launch_bounds__(256) void untile_gathered_kernel(uint32_t width, uint32_t height, uint32_t world, uint32_t self,
+                                                              uint32_t n_tiles, size_t px, size_t nbytes,
+                                                              const char* __restrict__ gathered, const char* __restrict__ mine,
+                                                              uint8_t* __restrict__ o_hit, float* __restrict__ o_depth,
+                                                              float* __restrict__ o_normal, uint32_t* __restrict__ o_prim) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const uint32_t p = tile % world, tile_local = tile / world;
+    const uint32_t tiles_x = (width + 7u) >> 3;
+    const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u), y = (tile / tiles_x) * 8u + (lane >> 3);
+    if (x >= width || y >= height) return;
+    const char* base = p == self ? mine : gathered + (size_t)p * nbytes;
+    const float* t_depth = reinterpret_cast<const float*>(base);
+    const float* t_normal = reinterpret_cast<const float*>(base + px * 4u);
+    const uint32_t* t_prim = reinterpret_cast<const uint32_t*>(base + px * 16u);
+    const uint8_t* t_hit = reinterpret_cast<const uint8_t*>(base + px * 20u);
+    const size_t s = (size_t)tile_local * 64u + lane, o = (size_t)y * width + x;
+    o_hit[o] = t_hit[s];
+    if (o_depth) o_depth[o] = t_depth[s];
+    if (o_normal) { o_normal[3 * o] = t_normal[3 * s]; o_normal[3 * o + 1] = t_normal[3 * s + 1]; o_normal[3 * o + 2] = t_normal[3 * s + 2]; }
+    if (o_prim) o_prim[o] = t_prim[s];
+}
+
 // ------------------------------------------------------- general path -----
 // Any union tree the reference state machine accepts (non-identity internal
 // trans_inverse, projective rows): the literal point chain of
@@ -1548,6 +1577,16 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
     if (st) return obb ? SDFGPU_RENDER(SDFGPU_BOUNDS_OBB, true) : SDFGPU_RENDER(SDFGPU_BOUNDS_AABB, true);
     return obb ? SDFGPU_RENDER(SDFGPU_BOUNDS_OBB, false) : SDFGPU_RENDER(SDFGPU_BOUNDS_AABB, false);
 #undef SDFGPU_RENDER
+}
+
+hipError_t launch_untile_gathered(uint32_t w, uint32_t h, uint32_t world, uint32_t self, size_t px, size_t nbytes,
+                                  const void* gathered, const void* mine, uint8_t* hit, float* depth, float* normal,
+                                  uint32_t* prim, hipStream_t s) {
+    const uint32_t n_tiles = ((w + 7u) / 8u) * ((h + 7u) / 8u);
+    if (n_tiles == 0) return hipSuccess;
+    untile_gathered_kernel<<<dim3((n_tiles + 3u) / 4u), dim3(256), 0, s>>>(w, h, world, self, n_tiles, px, nbytes, (const char*)gathered,
+                                                                          (const char*)mine, hit, depth, normal, prim);
+    return hipGetLastError();
 }
 
 hipError_t launch_untile(uint32_t w, uint32_t h, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,

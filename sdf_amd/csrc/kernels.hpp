@@ -85,4 +85,10 @@ hipError_t launch_untile(uint32_t w, uint32_t h, uint32_t tile_first, uint32_t t
                          const uint8_t* t_hit, const float* t_depth, const float* t_normal, const uint32_t* t_prim,
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, hipStream_t s);
 
+// Whole-frame assembly on the gathering rank in one launch: rank p's packed planes ([depth | normal | prim |
+// hit], `px` pixels each) at gathered + p * nbytes, the caller's own share at `mine`.
+hipError_t launch_untile_gathered(uint32_t w, uint32_t h, uint32_t world, uint32_t self, size_t px, size_t nbytes,
+                                  const void* gathered, const void* mine, uint8_t* hit, float* depth, float* normal,
+                                  uint32_t* prim, hipStream_t s);
+
 }  // namespace sdfgpu

@@ -190,6 +190,11 @@ class SdfGpu:
             )
         )
 
+    def untile_gathered_dev(self, width, height, world, rank, d_gathered, d_mine, d_hit, d_depth, d_normal, d_prim, stream=0):
+        """Whole-frame assembly in one launch from the ranks' packed tile buffers (sdfgpu_untile_gathered_dev)."""
+        self._check(self._lib.sdfgpu_untile_gathered_dev(self._h, width, height, world, rank, d_gathered, d_mine,
+                                                         d_hit, d_depth, d_normal, d_prim, stream))
+
     def render_stats(self, cam, width, height, mp):
         st = _ffi.Stats()
         self._check(self._lib.sdfgpu_render_stats(self._h, C.byref(cam), width, height, C.byref(mp), C.byref(st)))

@@ -251,6 +251,19 @@ def test_packed_planes_assembly_as_in_bench(gpu, world):
            "normal": o_normal.cpu().numpy().reshape(-1, 3), "prim": o_prim.cpu().numpy().view(np.uint32)}
     _compare(got, full)
 
+    # the same assembly in ONE launch (sdfgpu_untile_gathered_dev, what sdfgpu_render_frame_comm's root runs):
+    # rank `me`'s share is read from its own buffer, not from the gathered one (poisoned here to prove it)
+    assert S._ffi.load_library().sdfgpu_packed_share_bytes(w, h, world) == nbytes
+    me = world - 1
+    mine = gathered[me * nbytes:(me + 1) * nbytes].clone()
+    gathered[me * nbytes:(me + 1) * nbytes] = 0xA5
+    o2 = [torch.zeros_like(t) for t in (o_hit, o_depth, o_normal, o_prim)]
+    gpu.untile_gathered_dev(w, h, world, me, gathered.data_ptr(), mine.data_ptr(), *(t.data_ptr() for t in o2), stream)
+    torch.cuda.synchronize()
+    got = {"hit": o2[0].cpu().numpy(), "depth": o2[1].cpu().numpy(),
+           "normal": o2[2].cpu().numpy().reshape(-1, 3), "prim": o2[3].cpu().numpy().view(np.uint32)}
+    _compare(got, full)
+
 
 def _scale_leaf(buf, i, s):
     """Scale the whole world->primitive map of down-block i by s (a non-rigid leaf: its value is
