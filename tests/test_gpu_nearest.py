@@ -101,6 +101,28 @@ def test_duplicate_primitive_tie_goes_to_later(gpu):
     assert near_dup.any() and np.all(i[near_dup] == max(same))
 
 
+def test_points_exactly_on_centres_and_tiny_offsets(gpu):
+    # squared lengths of exactly 0 and far below 2^-96: the wavefronts holding such points take the
+    # compiler's full square-root expansion, the others the short one (kernels.hip, sqrt_rn) -- a batch
+    # mixes both, and a render marches through the same code
+    import itertools
+    b = S.SdfBuilder.primitive(S.SdfSphere(0.75)).transform(S.Transform.from_translation((0.0, 0.0, 0.0))).operation(S.SdfUnion(0.0))
+    centres = [(0.0, 0.0, 0.0)]
+    for c in itertools.product((-8.0, 8.0), (-4.0, 4.0), (-2.0, 2.0)):
+        centres.append(c)
+        b = b.with_(S.SdfBuilder.primitive(S.SdfSphere(0.5) if c[0] < 0 else S.SdfBox((0.5, 0.25, 1.0)))
+                    .transform(S.Transform.from_translation(c)))
+    buf = b.finalize().expanded().make_buffer()
+    pts = make_points(4096, 10.0, seed=21)
+    c = np.array(centres, np.float32)
+    pts[:9, :3] = c                                             # squared length exactly 0
+    pts[64:73, :3] = c + np.float32(1e-20)                      # normal-range coordinates, squared length denormal / 0
+    pts[128:137, :3] = c * np.float32(1.0) + np.array([1e-30, 0, 0], np.float32)
+    pts[200:209, :3] = c + np.array([0.0, 1e-15, 0.0], np.float32)   # squared length 1e-30 < 2^-96
+    for bounds in (S.BOUNDS_BVH, S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE):
+        _check(gpu, buf, pts, bounds)
+
+
 def test_w_not_one_is_rejected(gpu):
     gpu.upload_tree(S.random_scene_buffer(4, 1))
     p = make_points(8, 10.0, 1)
