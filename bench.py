@@ -62,8 +62,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed frames (200 x ~1.7 ms: a third of a second timed)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, help="BASELINE config (2, 3 or 4 are frames)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
     ap.add_argument("--knn-points", type=int, default=10_000_000)
-    ap.add_argument("--knn-steps", type=int, default=5)
+    ap.add_argument("--knn-steps", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget of the baseline leg")
     return ap.parse_args()
 
