@@ -4,9 +4,51 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <numeric>
+#include <system_error>
+#include <thread>
+
+#include <sched.h>
 
 namespace sdfhost {
+
+// Flattening is host work on the changing part of a scene (a rebuilt tree is re-expanded and re-flattened),
+// and both halves of it are recursions over independent subtrees: the two sides of the upper levels run
+// on separate threads.  Every node's arithmetic is its own, so the buffers are the same bytes whatever
+// the thread count (tests/test_host_builder.py).  Threads: the CPUs this process may run on, at most 16;
+// SDFGPU_BUILD_THREADS overrides (the same variable the upload in compact.cpp reads).
+static int host_forks() {
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)CPU_COUNT(&set));
+    if (const char* e = std::getenv("SDFGPU_BUILD_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+    hw = std::max(1u, std::min(hw, 16u));
+    int f = 0;
+    while ((2u << f) <= hw) ++f;
+    return f;
+}
+
+// run a() on a new thread beside b() when a thread can be had, else one after the other
+template <class A, class B>
+static void fork_join(bool parallel, A&& a, B&& b) {
+    if (parallel) {
+        std::thread t;
+        bool started = false;
+        try {
+            t = std::thread([&a] { a(); });
+            started = true;
+        } catch (const std::system_error&) {
+        }
+        if (started) {
+            b();
+            t.join();
+            return;
+        }
+    }
+    a();
+    b();
+}
 
 // ---------------------------------------------------------------- math ----
 
@@ -409,7 +451,7 @@ SdfOpSpecificBlock SdfUnion::get_ut_specific_block() const {
 // subset; they are mapped back through index_vec before recursing (the crate
 // passes them on as if they were slot indices).
 static ExpandedSdfNode union_recurse(const SdfUnion& self, const SdfNode& node,
-                                     const std::vector<size_t>& index_vec, const BuildOptions& o) {
+                                     const std::vector<size_t>& index_vec, const BuildOptions& o, int forks) {
     if (index_vec.size() == 1) return node.slots[index_vec[0]].expanded(o);
     std::vector<SdfBoundingBox> boxes;
     boxes.reserve(index_vec.size());
@@ -423,8 +465,11 @@ static ExpandedSdfNode union_recurse(const SdfUnion& self, const SdfNode& node,
     for (size_t k : halves.second) r.push_back(index_vec[k]);
     boxes.clear();
     boxes.shrink_to_fit();
-    return ExpandedSdfNode::operation(union_recurse(self, node, l, o), union_recurse(self, node, r, o),
-                                      merged, self.clone());
+    ExpandedSdfNode ln, rn;
+    const bool par = forks > 0 && l.size() >= 512 && r.size() >= 512;
+    fork_join(par, [&] { ln = union_recurse(self, node, l, o, par ? forks - 1 : forks); },
+              [&] { rn = union_recurse(self, node, r, o, par ? forks - 1 : forks); });
+    return ExpandedSdfNode::operation(std::move(ln), std::move(rn), merged, self.clone());
 }
 
 ExpandedSdfNode SdfUnion::expand(const SdfNode& node, const BuildOptions& o) const {
@@ -432,7 +477,7 @@ ExpandedSdfNode SdfUnion::expand(const SdfNode& node, const BuildOptions& o) con
     if (node.slots.empty()) return ExpandedSdfNode::null();          // elements.rs:174
     std::vector<size_t> all(node.slots.size());
     std::iota(all.begin(), all.end(), (size_t)0);
-    return union_recurse(*this, node, all, o);
+    return union_recurse(*this, node, all, o, host_forks());
 }
 
 // ---------------------------------------------------------- SdfCaaClone ----
@@ -500,47 +545,65 @@ ExpandedSdfNode ExpandedSdfNode::operation(ExpandedSdfNode l, ExpandedSdfNode r,
     return n;
 }
 
-static void make_buffer_recurse(SdfTreeBuffer& buf, const ExpandedSdfNode& root, const SdfBoundingBox& other_box,
-                                uint32_t level, bool parent_is_union, const BuildOptions& o) {
-    if (root.is_null()) return;                                  // node.rs:85-87
+// node.rs:75-138.  The crate pushes blocks as it recurses; the positions are known beforehand (a node is
+// followed by its left subtree, then its right one, in the down buffer; preceded by both in the up buffer),
+// so the blocks are written in place into arrays sized from the subtree counts, and the two sides of the
+// upper levels are filled by separate threads.
+static uint32_t count_nodes(const ExpandedSdfNode& n) {
+    if (n.is_null()) return 0;
+    if (n.is_primitive()) return 1;
+    const auto& s = *n.expanded_slots;
+    return 1u + count_nodes(s[0]) + count_nodes(s[1]);
+}
+
+// returns the number of nodes written; d0 / u0 = first free position of the down / up buffer
+static uint32_t make_buffer_recurse(SdfTreeBuffer& buf, const ExpandedSdfNode& root, const SdfBoundingBox& other_box,
+                                    uint32_t level, bool parent_is_union, const BuildOptions& o, uint32_t d0, uint32_t u0,
+                                    int forks) {
+    if (root.is_null()) return 0;                                // node.rs:85-87
     SdfElementInfo info = root.intern->get_info();
-    size_t this_ind = buf.downtree_buffer.size();
-    SdfOperationBlock blk;
+    SdfOperationBlock& blk = buf.downtree_buffer[d0];
     std::memset(&blk, 0, sizeof blk);
     blk.op_code = info.op_id;                                    // node.rs:97-106
     blk.is_primitive = info.is_primitive ? 1 : 0;
     blk.parent_is_union = parent_is_union ? 1 : 0;
-    blk.len = 0;
     blk.level = level;
     blk.op_specific = root.intern->get_dt_specific_block();
     blk.bounding_box = root.bbox.get_bbox_block();
     blk.other_box = other_box.get_bbox_block();
-    buf.downtree_buffer.push_back(blk);
 
+    uint32_t below = 0;
     if (!root.is_primitive()) {                                  // node.rs:108-122
         const auto& s = *root.expanded_slots;
         const bool u = root.is_union();
         // node.rs:113,119 pass each child's OWN box (C-2); optional sibling box.
         const SdfBoundingBox& ob0 = (o.sibling_other_box && !s[1].is_null()) ? s[1].bbox : s[0].bbox;
         const SdfBoundingBox& ob1 = (o.sibling_other_box && !s[0].is_null()) ? s[0].bbox : s[1].bbox;
-        make_buffer_recurse(buf, s[0], ob0, level + 1, u, o);
-        make_buffer_recurse(buf, s[1], ob1, level + 1, u, o);
+        const uint32_t n0 = count_nodes(s[0]);
+        uint32_t w0 = 0, w1 = 0;
+        const bool par = forks > 0 && n0 >= 1024 && !s[1].is_null() && !s[1].is_primitive();
+        fork_join(par, [&] { w0 = make_buffer_recurse(buf, s[0], ob0, level + 1, u, o, d0 + 1, u0, par ? forks - 1 : forks); },
+                  [&] { w1 = make_buffer_recurse(buf, s[1], ob1, level + 1, u, o, d0 + 1 + n0, u0 + n0, par ? forks - 1 : forks); });
+        below = w0 + w1;
     }
-    SdfOperationUptreeBlock ub;
+    SdfOperationUptreeBlock& ub = buf.uptree_buffer[u0 + below];
     std::memset(&ub, 0, sizeof ub);
     ub.op_code = info.op_id;                                     // node.rs:124-129
     ub.parent_is_union = parent_is_union ? 1 : 0;
     ub.op_specific = root.intern->get_ut_specific_block();
     ub.level = level;
-    buf.uptree_buffer.push_back(ub);
-    buf.downtree_buffer[this_ind].len = (uint32_t)(buf.downtree_buffer.size() - this_ind - 1);  // :131
+    blk.len = below;                                             // :131 (blocks pushed after this one)
+    return 1u + below;
 }
 
 SdfTreeBuffer ExpandedSdfNode::make_buffer(const BuildOptions& o) const {
     SdfTreeBuffer buf;
+    const uint32_t n = count_nodes(*this);
+    buf.downtree_buffer.resize(n);
+    buf.uptree_buffer.resize(n);
     SdfBoundingBox throwaway = SdfBoundingBox::zero();           // node.rs:134
-    make_buffer_recurse(buf, *this, throwaway, 1, false, o);     // node.rs:135
-    buf.buffer_len = (uint32_t)buf.downtree_buffer.size();       // node.rs:136
+    make_buffer_recurse(buf, *this, throwaway, 1, false, o, 0, 0, host_forks());   // node.rs:135
+    buf.buffer_len = n;                                          // node.rs:136
     return buf;
 }
 

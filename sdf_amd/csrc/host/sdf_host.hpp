@@ -21,6 +21,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/sdf_blocks.h"
@@ -170,9 +171,23 @@ struct SdfCaaClone : SdfElement {
 };
 
 // component.rs:80-96
+// Allocator whose resize() leaves trivially constructible elements uninitialised: make_buffer sizes the two
+// arrays (170 MB for 100k primitives) and then writes every block exactly once, from several threads; a
+// zero-fill pass over them first would cost as much as the fill.
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U>
+    struct rebind { using other = DefaultInitAlloc<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+
 struct SdfTreeBuffer {
-    std::vector<SdfOperationBlock> downtree_buffer;
-    std::vector<SdfOperationUptreeBlock> uptree_buffer;
+    std::vector<SdfOperationBlock, DefaultInitAlloc<SdfOperationBlock>> downtree_buffer;
+    std::vector<SdfOperationUptreeBlock, DefaultInitAlloc<SdfOperationUptreeBlock>> uptree_buffer;
     uint32_t buffer_len = 0;
 };
 

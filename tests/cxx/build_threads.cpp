@@ -1,5 +1,5 @@
 // build_threads.cpp -- test program (tests/test_build_threads.py compiles and runs it on the CPU).
-// The resident tree must not depend on how many threads built it: compact_tree is run on the same
+// Neither the flattened buffers nor the resident tree may depend on how many threads built them: compact_tree is run on the same
 // buffers with SDFGPU_BUILD_THREADS = 1, 2, 5 and 16 and every array and scalar is compared byte for
 // byte; and the first error reported must be the one with the lowest node index, whichever pass
 // (the threaded matrix check or the sequential structural pass) finds it.
@@ -47,6 +47,20 @@ int main() {
         sdfhost_expanded* ex = sdfhost_expanded_new(node, nullptr);
         sdfhost_buffer* buf = sdfhost_make_buffer(ex, nullptr);
         const uint32_t len = sdfhost_buffer_len(buf);
+        if (n >= 5000u) {
+            // the host side: expansion (SdfUnion::expand) and flattening (make_buffer) fork their upper levels too
+            for (const char* th : {"1", "3", "16"}) {
+                setenv("SDFGPU_BUILD_THREADS", th, 1);
+                sdfhost_expanded* ex2 = sdfhost_expanded_new(node, nullptr);
+                sdfhost_buffer* buf2 = sdfhost_make_buffer(ex2, nullptr);
+                CHECK(sdfhost_buffer_len(buf2) == len &&
+                          std::memcmp(sdfhost_buffer_downtree(buf2), sdfhost_buffer_downtree(buf), (size_t)len * sizeof(SdfOperationBlock)) == 0 &&
+                          std::memcmp(sdfhost_buffer_uptree(buf2), sdfhost_buffer_uptree(buf), (size_t)len * sizeof(SdfOperationUptreeBlock)) == 0,
+                      "n=%u: buffers flattened by %s threads differ", n, th);
+                sdfhost_buffer_free(buf2);
+                sdfhost_expanded_free(ex2);
+            }
+        }
         for (uint32_t bounds : {(uint32_t)SDFGPU_BOUNDS_AUTO, (uint32_t)SDFGPU_BOUNDS_AABB}) {
             CompactTree ref;
             std::string err;
