@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <exception>
 #include <numeric>
 #include <system_error>
 #include <thread>
@@ -29,20 +30,35 @@ static int host_forks() {
     return f;
 }
 
-// run a() on a new thread beside b() when a thread can be had, else one after the other
+// run a() on a new thread beside b() when a thread can be had, else one after the other.  An exception
+// of either side (an unset slot, an unfinished node: the builder reports those by throwing) is carried
+// back to the caller after both sides have finished; a()'s wins when both throw, as in the serial order.
 template <class A, class B>
 static void fork_join(bool parallel, A&& a, B&& b) {
     if (parallel) {
+        std::exception_ptr ea, eb;
         std::thread t;
         bool started = false;
         try {
-            t = std::thread([&a] { a(); });
+            t = std::thread([&a, &ea] {
+                try {
+                    a();
+                } catch (...) {
+                    ea = std::current_exception();
+                }
+            });
             started = true;
         } catch (const std::system_error&) {
         }
         if (started) {
-            b();
+            try {
+                b();
+            } catch (...) {
+                eb = std::current_exception();
+            }
             t.join();
+            if (ea) std::rethrow_exception(ea);
+            if (eb) std::rethrow_exception(eb);
             return;
         }
     }

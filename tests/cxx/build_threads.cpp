@@ -13,6 +13,7 @@
 #include "sdfgpu.h"
 #include "sdfhost.h"
 #include "gpu_tree.hpp"
+#include "host/sdf_host.hpp"
 
 using namespace sdfgpu;
 
@@ -93,6 +94,34 @@ int main() {
         sdfhost_buffer_free(buf);
         sdfhost_expanded_free(ex);
         sdfhost_node_free(node);
+    }
+    {
+        // A node that cannot be expanded (a clone without its child, elements.rs:260-262 unwraps slot 0), deep
+        // inside a union big enough for the expansion to fork: the error has to come back to the caller as an
+        // exception from whichever thread met it, not end the process there.
+        using namespace sdfhost;
+        setenv("SDFGPU_BUILD_THREADS", "8", 1);
+        SdfNode root(std::make_unique<SdfUnion>(0.f));
+        for (int i = 0; i < 6000; ++i) {
+            Transform t;
+            t.translation = Vec3((float)(i % 100) * 3.f, (float)((i / 100) % 60) * 3.f, (float)(i % 7));
+            if (i == 4321) {
+                SdfNode clone(std::make_unique<SdfCaaClone>(Vec3(4.f, 4.f, 4.f), Vec3(-1.f, -1.f, -1.f), Vec3(1.f, 1.f, 1.f)));
+                clone.set_slot(SdfBuilder::primitive(std::make_unique<SdfSphere>(1.f)).transform(t).finalize());
+                root.set_slot(std::move(clone));
+            } else {
+                root.set_slot(SdfBuilder::primitive(std::make_unique<SdfSphere>(1.f)).transform(t).finalize());
+            }
+        }
+        root.calc_bbox_assign();
+        root.slots[4321].slots.clear();   // boxes are in place; now take the clone's child away
+        bool threw = false;
+        try {
+            ExpandedSdfNode ex = root.expanded();
+        } catch (const std::exception& e) {
+            threw = true;
+        }
+        CHECK(threw, "expanding a union that holds an unexpandable node did not report an error");
     }
     if (failures == 0) std::printf("ok\n");
     return failures ? 1 : 0;
