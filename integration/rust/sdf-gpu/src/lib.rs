@@ -107,6 +107,15 @@ extern "C" {
     pub fn sdfgpu_render_frame_comm(ctx: *mut Ctx, comm: *mut Comm, cam: *const Camera, width: u32, height: u32,
                                     mp: *const MarchParams, root: c_int, d_hit: *mut u8, d_depth: *mut f32,
                                     d_normal_xyz: *mut f32, d_prim: *mut u32, stream: *mut c_void) -> c_int;
+    // the pieces of the same assembly for a host that brings its own collective: a rank's tile share into a
+    // packed buffer of sdfgpu_packed_share_bytes, every rank's buffer into the frame in one launch
+    pub fn sdfgpu_render_tiles_dev(ctx: *mut Ctx, cam: *const Camera, width: u32, height: u32, mp: *const MarchParams,
+                                   tile_first: u32, tile_stride: u32, tile_count: u32, d_hit: *mut u8, d_depth: *mut f32,
+                                   d_normal_xyz: *mut f32, d_prim: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn sdfgpu_packed_share_bytes(width: u32, height: u32, world: u32) -> usize;
+    pub fn sdfgpu_untile_gathered_dev(ctx: *mut Ctx, width: u32, height: u32, world: u32, self_rank: u32,
+                                      d_gathered: *const c_void, d_mine: *const c_void, d_hit: *mut u8, d_depth: *mut f32,
+                                      d_normal_xyz: *mut f32, d_prim: *mut u32, stream: *mut c_void) -> c_int;
     fn sdfgpu_nearest(ctx: *mut Ctx, pts_xyzw: *const f32, n: usize, out_dist: *mut f32, out_prim: *mut u32) -> c_int;
     fn sdfgpu_knn(ctx: *mut Ctx, pts_xyzw: *const f32, n: usize, k: u32, out_dist: *mut f32, out_prim: *mut u32) -> c_int;
     fn sdfgpu_box_bounds(ctx: *mut Ctx, bbox: *const SdfBoundingBoxBlock, pts_xyzw: *const f32, n: usize,
