@@ -31,13 +31,12 @@ struct sdfgpu_ctx {
     std::string err;
     // grow-only scratch for the host-pointer entry points
     DevBuf in, out_a, out_b, out_c, out_d, stats;
-    // Morton reordering of query batches (sort.hip)
-    DevBuf keys_a, keys_b, idx_a, idx_b, sort_tmp;
-    // multi-pass march (ray compaction)
-    // one scratch per stream that has rendered: frames in flight on different streams
-    // must not share pass state
+    // One scratch set per stream the context has worked on: frames and query batches in flight on
+    // different streams must not share pass state, tile schedules or sort buffers.
     struct MarchScratch {
         hipStream_t stream;
+        // spatial reordering of query batches (sort.hip): keys in / out, permutation in / out, radix sort storage
+        DevBuf keys_a, keys_b, idx_a, idx_b, sort_tmp;
         DevBuf buf;                 // pass state of the multi-pass march (compaction)
         // longest-first tile order from the costs the previous frame on this stream recorded
         DevBuf order;               // [cost | iota | sorted keys | order] x tiles, then the sort's temp storage
@@ -121,7 +120,9 @@ int check_march(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
     return SDFGPU_OK;
 }
 
-// Morton permutation of a device point batch (nullptr when reordering is off
+sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream);
+
+// Space-filling-curve permutation of a device point batch (nullptr when reordering is off
 // or not worth it).  Scratch is grow-only, so steady-state calls allocate nothing.
 constexpr size_t REORDER_MIN_POINTS = 2048;
 int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const uint32_t** order, bool use_static = false) {
@@ -151,15 +152,17 @@ int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const
         idx_b = (uint32_t*)(base + 3 * arr);
         temp = base + 4 * arr;
     } else {
+        // the buffers of the stream the batch runs on: batches in flight on different streams do not share them
+        sdfgpu_ctx::MarchScratch* ms = stream_scratch(c, s);
         int rc;
-        if ((rc = reserve(c, c->keys_a, n * 4)) || (rc = reserve(c, c->keys_b, n * 4)) || (rc = reserve(c, c->idx_a, n * 4)) ||
-            (rc = reserve(c, c->idx_b, n * 4)) || (rc = reserve(c, c->sort_tmp, tmp)))
+        if ((rc = reserve(c, ms->keys_a, n * 4)) || (rc = reserve(c, ms->keys_b, n * 4)) || (rc = reserve(c, ms->idx_a, n * 4)) ||
+            (rc = reserve(c, ms->idx_b, n * 4)) || (rc = reserve(c, ms->sort_tmp, tmp)))
             return rc;
-        keys_a = (uint32_t*)c->keys_a.p;
-        keys_b = (uint32_t*)c->keys_b.p;
-        idx_a = (uint32_t*)c->idx_a.p;
-        idx_b = (uint32_t*)c->idx_b.p;
-        temp = c->sort_tmp.p;
+        keys_a = (uint32_t*)ms->keys_a.p;
+        keys_b = (uint32_t*)ms->keys_b.p;
+        idx_a = (uint32_t*)ms->idx_a.p;
+        idx_b = (uint32_t*)ms->idx_b.p;
+        temp = ms->sort_tmp.p;
     }
     HIP_TRY(c, launch_morton_order(d_pts, (uint32_t)n, lo, hi, keys_a, keys_b, idx_a, idx_b, temp, tmp, s));
     *order = idx_b;
@@ -260,8 +263,8 @@ sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream) {
             if (c->march[i].stamp < c->march[lru].stamp) lru = i;
         sdfgpu_ctx::MarchScratch& old = c->march[lru];
         if (hipStreamSynchronize(old.stream) != hipSuccess) (void)hipDeviceSynchronize();   // the stream may be gone
-        if (old.buf.p) (void)hipFree(old.buf.p);
-        if (old.order.p) (void)hipFree(old.order.p);
+        for (DevBuf* b : {&old.buf, &old.order, &old.keys_a, &old.keys_b, &old.idx_a, &old.idx_b, &old.sort_tmp})
+            if (b->p) (void)hipFree(b->p);
         old = sdfgpu_ctx::MarchScratch();
         std::swap(old, c->march.back());
     }
@@ -407,8 +410,7 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_tree(c);
-    for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats, &c->keys_a, &c->keys_b, &c->idx_a,
-                      &c->idx_b, &c->sort_tmp})
+    for (DevBuf* b : {&c->in, &c->out_a, &c->out_b, &c->out_c, &c->out_d, &c->stats})
         if (b->p) (void)hipFree(b->p);
     if (c->aux) {
         (void)hipStreamSynchronize(c->aux);
@@ -421,10 +423,9 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
         if (c->ev_start) (void)hipEventDestroy(c->ev_start);
         (void)hipStreamDestroy(c->aux);
     }
-    for (auto& m : c->march) {
-        if (m.buf.p) (void)hipFree(m.buf.p);
-        if (m.order.p) (void)hipFree(m.order.p);
-    }
+    for (auto& m : c->march)
+        for (DevBuf* b : {&m.buf, &m.order, &m.keys_a, &m.keys_b, &m.idx_a, &m.idx_b, &m.sort_tmp})
+            if (b->p) (void)hipFree(b->p);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -105,3 +105,38 @@ def test_chunked_pipeline_is_invisible(gpu):
     d0, i0 = O.nearest(buf, pts[sel].cpu().numpy(), O.MODE_TUNED, threads=8)
     assert np.array_equal(bits(res[4][0][sel].cpu().numpy()), bits(d0))
     assert np.array_equal(res[4][1][sel].cpu().numpy().view(np.uint32), i0)
+
+
+def test_batches_in_flight_on_several_streams(gpu):
+    # query batches of ONE context in flight on different streams: each stream has its own sort buffers
+    # (keys, permutation, radix storage), so the batches cannot disturb each other
+    import torch
+
+    n_prims, n = 3000, 300_000
+    buf = S.random_scene_buffer(n_prims, 0x57E)
+    gpu.upload_tree(buf)
+    L = S.default_extent(n_prims)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sets = [torch.from_numpy(make_points(n - 1000 * j, L, seed=300 + j)).cuda() for j in range(3)]
+    torch.cuda.synchronize()
+    want = []
+    for p in sets:                      # one after the other on the context's own stream
+        m = p.shape[0]
+        want.append((gpu.nearest(p.cpu().numpy()), gpu.knn(p.cpu().numpy(), 8)))
+    outs = []
+    for rnd in range(2):                # interleaved, nothing synchronised in between
+        for j, (st, p) in enumerate(zip(streams, sets)):
+            m = p.shape[0]
+            d1 = torch.empty(m, dtype=torch.float32, device="cuda")
+            i1 = torch.empty(m, dtype=torch.int32, device="cuda")
+            d8 = torch.empty(m * 8, dtype=torch.float32, device="cuda")
+            i8 = torch.empty(m * 8, dtype=torch.int32, device="cuda")
+            gpu.nearest_dev(p.data_ptr(), m, d1.data_ptr(), i1.data_ptr(), st.cuda_stream)
+            gpu.knn_dev(p.data_ptr(), m, 8, d8.data_ptr(), i8.data_ptr(), st.cuda_stream)
+            outs.append((j, d1, i1, d8, i8))
+    torch.cuda.synchronize()
+    for j, d1, i1, d8, i8 in outs:
+        (wd, wi), (wkd, wki) = want[j]
+        assert np.array_equal(bits(d1.cpu().numpy()), bits(wd)) and np.array_equal(i1.cpu().numpy().view(np.uint32), wi)
+        assert np.array_equal(bits(d8.cpu().numpy().reshape(-1, 8)), bits(wkd))
+        assert np.array_equal(i8.cpu().numpy().view(np.uint32).reshape(-1, 8), wki)
