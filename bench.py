@@ -209,6 +209,21 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
     gpu.set_reorder(False)
     e_off, e1_off = timed(step_s), timed(step1_s)
     gpu.set_reorder(True)
+    # two batches in flight: consecutive batches alternate between two streams of the same context (each
+    # stream has its own sort buffers and its own outputs here), so the bandwidth-bound sort of one batch
+    # runs beside the VALU-bound walk of the other -- the query-side analogue of the frame leg's frames in flight
+    s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    o2 = [(torch.empty(n * k, dtype=torch.float32, device=dev), torch.empty(n * k, dtype=torch.int32, device=dev)) for _ in range(2)]
+    flip = [0]
+
+    def step_two():
+        j = flip[0] & 1
+        flip[0] += 1
+        gpu.knn_dev(pts.data_ptr(), n, k, o2[j][0].data_ptr(), o2[j][1].data_ptr(), s2[j].cuda_stream)
+
+    e_two = timed(step_two)
+    out["two_batches_in_flight"] = {"value": n_total * a.knn_steps / e_two, "ms_per_step": e_two / a.knn_steps * 1e3, "unit": "queries/s",
+                                    "note": "the same unsorted batch, consecutive calls alternating between two streams of one context"}
     out["presorted"] = {
         "points": "the same points, sorted along the Hilbert curve by the caller before the call (workloads.hilbert_keys)",
         "k8_reorder_on": {"value": n_total * a.knn_steps / e_on, "ms_per_step": e_on / a.knn_steps * 1e3},
