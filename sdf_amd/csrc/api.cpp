@@ -37,6 +37,7 @@ struct sdfgpu_ctx {
         hipStream_t stream;
         // spatial reordering of query batches (sort.hip): keys in / out, permutation in / out, radix sort storage
         DevBuf keys_a, keys_b, idx_a, idx_b, sort_tmp;
+        DevBuf eye;                 // 16 bytes: result of the frame's one walk from the eye (kernels.hpp, RenderScratch::eye)
         DevBuf buf;                 // pass state of the multi-pass march (compaction)
         // longest-first tile order from the costs the previous frame on this stream recorded
         DevBuf order;               // [cost | iota | sorted keys | order] x tiles, then the sort's temp storage
@@ -263,7 +264,7 @@ sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream) {
             if (c->march[i].stamp < c->march[lru].stamp) lru = i;
         sdfgpu_ctx::MarchScratch& old = c->march[lru];
         if (hipStreamSynchronize(old.stream) != hipSuccess) (void)hipDeviceSynchronize();   // the stream may be gone
-        for (DevBuf* b : {&old.buf, &old.order, &old.keys_a, &old.keys_b, &old.idx_a, &old.idx_b, &old.sort_tmp})
+        for (DevBuf* b : {&old.buf, &old.order, &old.eye, &old.keys_a, &old.keys_b, &old.idx_a, &old.idx_b, &old.sort_tmp})
             if (b->p) (void)hipFree(b->p);
         old = sdfgpu_ctx::MarchScratch();
         std::swap(old, c->march.back());
@@ -313,6 +314,11 @@ int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint3
     int rc = march_setup(c, stream, tile_count, mp->max_steps, &rs, &pb);
     if (rc) return rc;
     sdfgpu_ctx::MarchScratch* ms = nullptr;
+    if (!c->tree.gen && mp->t_min == 0.0f) {   // the walk from the eye, once per frame (kernels.hip, eye_walk_kernel)
+        sdfgpu_ctx::MarchScratch* es = stream_scratch(c, stream);
+        if ((rc = reserve(c, es->eye, 16))) return rc;
+        rs.eye = (float*)es->eye.p;
+    }
     uint32_t *cost = nullptr, *iota = nullptr, *keys = nullptr, *order = nullptr;
     void* temp = nullptr;
     size_t temp_bytes = 0;
@@ -424,7 +430,7 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
         (void)hipStreamDestroy(c->aux);
     }
     for (auto& m : c->march)
-        for (DevBuf* b : {&m.buf, &m.order, &m.keys_a, &m.keys_b, &m.idx_a, &m.idx_b, &m.sort_tmp})
+        for (DevBuf* b : {&m.buf, &m.order, &m.eye, &m.keys_a, &m.keys_b, &m.idx_a, &m.idx_b, &m.sort_tmp})
             if (b->p) (void)hipFree(b->p);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -777,6 +783,11 @@ int sdfgpu_render_stats(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uin
     RenderScratch rs;
     std::vector<uint32_t> pb;
     if ((rc = march_setup(c, c->stream, tiles, mp->max_steps, &rs, &pb))) return rc;
+    if (!c->tree.gen && mp->t_min == 0.0f) {   // count what the timed kernel does: one walk from the eye per frame
+        sdfgpu_ctx::MarchScratch* es = stream_scratch(c, c->stream);
+        if ((rc = reserve(c, es->eye, 16))) return rc;
+        rs.eye = (float*)es->eye.p;
+    }
     HIP_TRY(c, launch_render(c->tree, *cam, w, h, *mp, 0, 1, tiles, true, rs, pb.data(), (uint32_t)pb.size(),
                              (uint8_t*)c->out_a.p, nullptr, nullptr, nullptr, (sdfgpu_stats*)c->stats.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->stats.p, sizeof(sdfgpu_stats), hipMemcpyDeviceToHost, c->stream));

@@ -780,7 +780,22 @@ struct PassArgs {
     uint32_t* out_counts;
     const uint32_t* tile_order;       // first pass: wave w renders tile tile_order[w] (null: tile w)
     uint32_t* tile_cost;              // first pass: min(steps the wave ran, 255) per tile (null: not recorded)
+    const float4* eye;                // first pass, t_min = 0: (best, bid bits, lb_key, second) of the walk from the eye, or null
 };
+
+// The first march step of every ray of a frame stands at the same point when t_min = 0: the eye.  Its walk
+// (45 internal nodes and 3 primitives per wavefront on the bench frame, 4 % of a frame's visits) is made once,
+// by one wavefront whose 64 lanes all hold that point -- identical needs, so the nodes visited, the bounds kept
+// and the result are what each tile's own first walk would have produced.
+template <int MODE>
+__global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, float ey, float ez, float4* __restrict__ out) {
+    extern __shared__ float smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    AccTracked acc{__builtin_inff(), SDF_NO_PRIM, __builtin_inff(), __builtin_inff()};
+    WaveCounters wc;
+    nn_traverse<MODE, 0>(T, ex, ey, ez, ~0ull, T.skip_ext, acc, smem, lane, wc);
+    if (lane == 0) *out = make_float4(acc.best, __builtin_bit_cast(float, acc.bid), acc.lb_key, acc.second);
+}
 
 template <int MODE, bool COUNT, bool FIRST>
 __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_camera cam, uint32_t width, uint32_t height,
@@ -882,6 +897,10 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
         c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
     }
+    // FIRST pass with the eye's walk at hand: taken instead of this wavefront's own first walk when every
+    // marching lane really stands at the eye (a degenerate ray direction would put a lane elsewhere)
+    bool eye_step = false;
+    if constexpr (FIRST) eye_step = pa.eye != nullptr;
     for (;;) {
         // Wave masks are formed from the ballots of the individual compares: a ballot of a compare IS the
         // compare's own mask, while a ballot of a combined flag is materialised per lane and compared again.
@@ -912,9 +931,24 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         } else {
             // no marching lane can certify: one walk for all of them
             const unsigned long long dmask = m_active;
-            if constexpr (COUNT) wc.wave_walks += 1;
             AccTracked acc{best, bid, __builtin_inff(), __builtin_inff()};
-            nn_traverse<MODE, COUNT>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
+            bool shared = false;
+            if constexpr (FIRST) {
+                if (eye_step) {
+                    const bool at_eye = (px == ox) & (py == oy) & (pz == oz) & !seeded;
+                    shared = (__builtin_amdgcn_ballot_w64(at_eye) & dmask) == dmask;
+                }
+            }
+            if (shared) {
+                const float4 e = *pa.eye;
+                acc.best = e.x;
+                acc.bid = __builtin_bit_cast(uint32_t, e.y);
+                acc.lb_key = e.z;
+                acc.second = e.w;
+            } else {
+                if constexpr (COUNT) wc.wave_walks += 1;
+                nn_traverse<MODE, COUNT>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
+            }
             best = acc.best;
             bid = acc.bid;
             // a bound, not a result: the hardware square root (1 ulp) is inside the 0.9996
@@ -941,6 +975,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         last = adv ? bid : last;
         s += adv ? 1u : 0u;
         state = hit_now ? 1u : ((go & (tn > mp.t_max)) ? 2u : state);
+        eye_step = false;   // only the very first iteration of a ray's march can stand at the eye
         if (!cheap) {   // the walk may have changed `last`: fetch its record once
             if ((state == 0u) & (s < pa.step_end) & (last != SDF_NO_PRIM)) {   // (an empty tree has no nearest primitive)
                 const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
@@ -1535,6 +1570,14 @@ static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam,
         pa.out_counts = rs.counts;
         pa.tile_order = (n_bounds == 2 && !COUNT) ? rs.tile_order : nullptr;
         pa.tile_cost = (n_bounds == 2 && !COUNT) ? rs.tile_cost : nullptr;
+        pa.eye = nullptr;
+        if (k == 0 && rs.eye && mp.t_min == 0.0f) {
+            eye_walk_kernel<MODE><<<dim3(1), dim3(64), (size_t)d.stack_depth * 64 * sizeof(float), s>>>(v, cam.eye[0], cam.eye[1], cam.eye[2],
+                                                                                                         (float4*)rs.eye);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            pa.eye = (const float4*)rs.eye;
+        }
         if (k == 0)
             render_pass_kernel<MODE, COUNT, true><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
                                                                           row_major ? 1u : 0u, pa, hit, depth, normal, prim, st);

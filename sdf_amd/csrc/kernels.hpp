@@ -63,6 +63,9 @@ struct RenderScratch {
     // tile range; every wave records min(march steps it ran, 255) in tile_cost[its tile].  Either may be null.
     const uint32_t* tile_order = nullptr;
     uint32_t* tile_cost = nullptr;
+    // 16 bytes: the result of the walk from the eye (every ray's first march step stands there when t_min = 0),
+    // made once per frame by a one-wavefront kernel instead of once per tile.  Null: every tile walks it itself.
+    float* eye = nullptr;
 };
 size_t tile_sort_temp_bytes(uint32_t n);
 hipError_t launch_iota(uint32_t* v, uint32_t n, hipStream_t s);
