@@ -331,3 +331,38 @@ def test_more_streams_than_scratch_slots(gpu):
             assert np.array_equal(bits(o[1].cpu().numpy()), bits(want["depth"])), f"stream {k}"
     finally:
         gpu.set_compaction(False)
+
+
+def test_first_march_step_shared_or_not(gpu):
+    # With t_min = 0 every ray's first step stands at the eye and the walk from there is made once per frame
+    # (kernels.hip, eye_walk_kernel); with any other t_min, or for a ray whose direction is degenerate, the
+    # wavefronts walk for themselves.  All of it must render what the oracle renders.
+    n, w, h = 300, 96, 64
+    buf = S.random_scene_buffer(n, 0xE7E)
+    L = S.default_extent(n)
+    gpu.upload_tree(buf)
+    cam = S.camera_look_at((0, 0, -2.5 * L), (0, 0, 0), (0, 1, 0), math.pi / 4, w, h)
+    for t_min in (0.0, 0.25 * L, -3.0):
+        mp = S.march_params(max_steps=96, eps_hit=1e-3, t_min=t_min, t_max=6 * L, normal_h=1e-4)
+        _compare(gpu.render(cam, w, h, mp), O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8))
+    # the eye inside the scene, next to (and for some seeds inside) primitives: the shared first step can hit
+    cam_in = S.camera_look_at((0.3, -0.2, 0.1), (0, 0, 5.0), (0, 1, 0), math.pi / 3, w, h)
+    mp = S.march_params(max_steps=96, eps_hit=1e-3, t_min=0.0, t_max=6 * L, normal_h=1e-4)
+    _compare(gpu.render(cam_in, w, h, mp), O.render(buf, cam_in, w, h, mp, mode=O.MODE_TUNED, threads=8))
+    # multi-pass march: only the first pass starts at the eye
+    gpu.set_compaction(True)
+    try:
+        _compare(gpu.render(cam, w, h, mp), O.render(buf, cam, w, h, mp, mode=O.MODE_TUNED, threads=8))
+    finally:
+        gpu.set_compaction(False)
+    # a pixel whose direction is the zero vector (image plane origin = eye): that ray's direction is NaN, its
+    # lane does not stand at the eye, and its wavefront must not take the shared step for it
+    import copy
+    bad = copy.copy(cam)
+    for a in range(3):
+        bad.origin[a] = bad.eye[a]
+    img, ref = gpu.render(bad, w, h, mp), O.render(buf, bad, w, h, mp, mode=O.MODE_TUNED, threads=8)
+    assert np.array_equal(img["hit"], ref["hit"]) and np.array_equal(img["prim"], ref["prim"])
+    ok = np.isfinite(ref["depth"]) & np.isfinite(img["depth"])
+    assert np.array_equal(bits(img["depth"])[ok], bits(ref["depth"])[ok])
+    assert np.array_equal(np.isnan(img["depth"]), np.isnan(ref["depth"]))
