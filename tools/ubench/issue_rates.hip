@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) 
         } else if constexpr (KIND == 20) {  // compare + 2 selects, as a compare-exchange does
             REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_cndmask_b32 %3, %1, %0, vcc\n v_add_f32 %4, %4, %2"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");)
+        } else if constexpr (KIND >= 21 && KIND <= 23) {   // 32 VALU with part of the wavefront masked off in EXEC
+            // (does a half / quarter-empty EXEC make a VALU instruction cheaper?  21: lanes 0..31, 22: lane 0 only, 23: lanes 0..15)
+            const unsigned long long m = KIND == 21 ? 0xFFFFFFFFull : (KIND == 22 ? 1ull : 0xFFFFull);
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, %1" : "=&s"(saved) : "s"(m));
+            REP8(asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_add_f32 %4, %4, %1"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : );)
+            asm volatile("s_mov_b64 exec, %0" : : "s"(saved));
         } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
             REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
         }
@@ -179,6 +187,9 @@ int main() {
     run<18>("32 v_cndmask sgpr mask", 32, 0);
     run<19>("32 v_cndmask vcc (s_mov)", 32, 0);
     run<20>("cmp + 2 cndmask + add", 32, 0);
+    run<21>("32 VALU, EXEC = lanes 0..31", 32, 0);
+    run<23>("32 VALU, EXEC = lanes 0..15", 32, 0);
+    run<22>("32 VALU, EXEC = lane 0", 32, 0);
     run<2>("32 VALU + 32 SALU", 32, 32);
     run<3>("32 VALU + 16 SALU", 32, 16);
     return 0;
