@@ -383,6 +383,12 @@ pop:
 // over.  s[48:63] hold the internal node's record (and, on exit, the leaf's: the same registers, so the block costs
 // 18 fixed SGPRs, placed low so that they do not raise the kernel's SGPR count), s64/s65 take the prefetches.  Hazards: no VALU-written SGPR is read by a VALU here (gfx950 needs
 // two wait states for that); lane masks go VALU->SALU->VALU, which interlocks.
+//
+// Operand order: in a loop of nothing else, a VOP3-encoded instruction with its SGPR operand in src1 issues
+// at 1.76 ns per wavefront on gfx950 and the same instruction with the SGPR in src0 at 1.01 ns, like a plain
+// VOP2 (tools/ubench/issue_rates.hip, KINDs 14 / 26-31).  Hence `v_add -h, |a| clamp` for |a| - h (same
+// bits: a - b = a + (-b)) rather than `v_sub |a|, h clamp` -- although in this block, three at a time between
+// other instructions, the two forms measured the same (frame 1.728 vs 1.735 ms).
 constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 
 #define SDFGPU_WALK_ASM(LBMIN_K0, LBMIN_K1, LBMIN_A, PREFETCH, CNT_INNER, CNT_LEAF)                                                   \
@@ -399,18 +405,18 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "v_subrev_f32 %[a], s48, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s49, %[py]\n\t"                                                              \
     "v_subrev_f32 %[c], s50, %[pz]\n\t"                                                              \
-    "v_sub_f32 %[a], |%[a]|, s51 clamp\n\t"                                                          \
-    "v_sub_f32 %[b], |%[b]|, s52 clamp\n\t"                                                          \
-    "v_sub_f32 %[c], |%[c]|, s53 clamp\n\t"                                                          \
+    "v_add_f32 %[a], -s51, |%[a]| clamp\n\t"                                                          \
+    "v_add_f32 %[b], -s52, |%[b]| clamp\n\t"                                                          \
+    "v_add_f32 %[c], -s53, |%[c]| clamp\n\t"                                                          \
     "v_mul_f32 %[k0], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k0], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k0], %[c], %[c]\n\t"                                                               \
     "v_subrev_f32 %[a], s54, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s55, %[py]\n\t"                                                              \
     "v_subrev_f32 %[c], s56, %[pz]\n\t"                                                              \
-    "v_sub_f32 %[a], |%[a]|, s57 clamp\n\t"                                                          \
-    "v_sub_f32 %[b], |%[b]|, s58 clamp\n\t"                                                          \
-    "v_sub_f32 %[c], |%[c]|, s59 clamp\n\t"                                                          \
+    "v_add_f32 %[a], -s57, |%[a]| clamp\n\t"                                                          \
+    "v_add_f32 %[b], -s58, |%[b]| clamp\n\t"                                                          \
+    "v_add_f32 %[c], -s59, |%[c]| clamp\n\t"                                                          \
     "v_mul_f32 %[k1], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k1], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k1], %[c], %[c]\n\t"                                                               \

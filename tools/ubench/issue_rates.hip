@@ -125,6 +125,38 @@ __global__ __launch_bounds__(256) void k(long long* out, int iters, float seed) 
             REP8(asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_add_f32 %4, %4, %1"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : );)
             asm volatile("s_mov_b64 exec, %0" : : "s"(saved));
+        } else if constexpr (KIND == 24) {  // 32 v_sub_f32 |a|, s clamp in the SDWA encoding (is it the modifiers or the 8-byte encoding that costs?)
+            float sg = __builtin_amdgcn_readfirstlane(seed);
+            REP8(asm volatile("v_sub_f32_sdwa %0, |%0|, %4 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+                              "v_sub_f32_sdwa %1, |%1|, %4 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+                              "v_sub_f32_sdwa %2, |%2|, %4 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+                              "v_sub_f32_sdwa %3, |%3|, %4 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(sg));)
+        } else if constexpr (KIND == 25) {  // 32 plain VOP2 adds with a 32-bit literal (8-byte encoding, no modifiers)
+            REP8(asm volatile("v_add_f32 %0, 0x3f8ccccd, %0\n v_add_f32 %1, 0x3f8ccccd, %1\n v_add_f32 %2, 0x3f8ccccd, %2\n v_add_f32 %3, 0x3f8ccccd, %3"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : );)
+        } else if constexpr (KIND == 26) {  // 32 VOP3 v_sub |a|, v (modifier, VGPR operands only)
+            REP8(asm volatile("v_sub_f32_e64 %0, |%0|, %4\n v_sub_f32_e64 %1, |%1|, %4\n v_sub_f32_e64 %2, |%2|, %4\n v_sub_f32_e64 %3, |%3|, %4"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));)
+        } else if constexpr (KIND == 27) {  // 32 VOP3-encoded plain adds, VGPR operands, no modifier
+            REP8(asm volatile("v_add_f32_e64 %0, %0, %4\n v_add_f32_e64 %1, %1, %4\n v_add_f32_e64 %2, %2, %4\n v_add_f32_e64 %3, %3, %4"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));)
+        } else if constexpr (KIND == 28) {  // 32 VOP2 subs with an SGPR in src0
+            float sg = __builtin_amdgcn_readfirstlane(seed);
+            REP8(asm volatile("v_subrev_f32_e32 %0, %4, %0\n v_subrev_f32_e32 %1, %4, %1\n v_subrev_f32_e32 %2, %4, %2\n v_subrev_f32_e32 %3, %4, %3"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(sg));)
+        } else if constexpr (KIND == 29) {  // 32 VOP3 v_add -s, |a| clamp: the SGPR in src0
+            float sg = __builtin_amdgcn_readfirstlane(seed);
+            REP8(asm volatile("v_add_f32_e64 %0, -%4, |%0| clamp\n v_add_f32_e64 %1, -%4, |%1| clamp\n v_add_f32_e64 %2, -%4, |%2| clamp\n v_add_f32_e64 %3, -%4, |%3| clamp"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(sg));)
+        } else if constexpr (KIND == 30) {  // 32 VOP3 v_sub s, |a|: SGPR in src0, modifier on src1
+            float sg = __builtin_amdgcn_readfirstlane(seed);
+            REP8(asm volatile("v_sub_f32_e64 %0, %4, |%0|\n v_sub_f32_e64 %1, %4, |%1|\n v_sub_f32_e64 %2, %4, |%2|\n v_sub_f32_e64 %3, %4, |%3|"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(sg));)
+        } else if constexpr (KIND == 31) {  // 32 VOP3 v_add s, v without any modifier
+            float sg = __builtin_amdgcn_readfirstlane(seed);
+            REP8(asm volatile("v_add_f32_e64 %0, %4, %0\n v_add_f32_e64 %1, %4, %1\n v_add_f32_e64 %2, %4, %2\n v_add_f32_e64 %3, %4, %3"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(sg));)
         } else if constexpr (KIND == 5) {   // 32 dependent VALU (latency chain)
             REP32(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));)
         }
@@ -187,6 +219,14 @@ int main() {
     run<18>("32 v_cndmask sgpr mask", 32, 0);
     run<19>("32 v_cndmask vcc (s_mov)", 32, 0);
     run<20>("cmp + 2 cndmask + add", 32, 0);
+    run<24>("32 v_sub |a|, s clamp (SDWA)", 32, 0);
+    run<25>("32 v_add literal (VOP2, 8 B)", 32, 0);
+    run<26>("32 v_sub |a|, v (VOP3)", 32, 0);
+    run<27>("32 v_add_e64 v, v (VOP3)", 32, 0);
+    run<28>("32 v_subrev s, v (VOP2)", 32, 0);
+    run<29>("32 v_add -s, |a| clamp (VOP3)", 32, 0);
+    run<30>("32 v_sub s, |a| (VOP3)", 32, 0);
+    run<31>("32 v_add_e64 s, v (VOP3)", 32, 0);
     run<21>("32 VALU, EXEC = lanes 0..31", 32, 0);
     run<23>("32 VALU, EXEC = lanes 0..15", 32, 0);
     run<22>("32 VALU, EXEC = lane 0", 32, 0);
