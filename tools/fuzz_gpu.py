@@ -9,13 +9,15 @@ from oracle import oracle as O
 
 def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
-def run(seed, iters, gpu=None, log=print):
+def run(seed, iters, gpu=None, log=print, heavy=False):
+  """heavy: larger trees now and then, a render on every other scene with the camera sometimes inside the
+  scene, t_min zero or not, and a varying step cap (the soak run, tools/soak_gpu.sh)."""
   rng = np.random.default_rng(seed)
   gpu = gpu or S.SdfGpu(0)
   bad = 0
   last_pos = None
   for it in range(iters):
-      n = int(rng.choice([1, 2, 3, 5, 17, 64, 257, 1000]))
+      n = int(rng.choice([1, 2, 3, 5, 17, 64, 257, 1000] + ([4000] if heavy else [])))
       scale = float(rng.choice([1e-3, 1.0, 50.0, 1e4]))
       offset = rng.choice([0.0, 1e3, -1e5]) * rng.uniform(-1, 1, 3)
       parts = []
@@ -53,11 +55,18 @@ def run(seed, iters, gpu=None, log=print):
           if not (np.array_equal(bits(dk), bits(dk0)) and np.array_equal(ik, ik0)):
               log(f"MISMATCH knn it={it} n={n} scale={scale} mode={mode} k={k}")
               bad += 1
-      if it % 6 == 0:
+      if it % (2 if heavy else 6) == 0:
           w, h = 72, 40
           L = scale * 20
-          cam = S.camera_look_at(tuple(float(v) for v in offset + np.array([0.3 * L, 0.2 * L, -3.0 * L])), tuple(float(v) for v in offset), (0, 1, 0), 0.8, w, h)
-          mp = S.march_params(max_steps=64, eps_hit=1e-3 * scale, t_min=0.0, t_max=8 * L, normal_h=1e-3 * scale)
+          eye = np.array([0.3 * L, 0.2 * L, -3.0 * L])
+          steps, t_min = 64, 0.0
+          if heavy:
+              if rng.random() < 0.4:
+                  eye = L * rng.uniform(-0.8, 0.8, 3)          # inside the scene, perhaps inside a primitive
+              steps = int(rng.choice([16, 64, 200]))
+              t_min = float(rng.choice([0.0, 0.0, 0.5 * L]))
+          cam = S.camera_look_at(tuple(float(v) for v in offset + eye), tuple(float(v) for v in offset), (0, 1, 0), 0.8, w, h)
+          mp = S.march_params(max_steps=steps, eps_hit=1e-3 * scale, t_min=t_min, t_max=8 * L, normal_h=1e-3 * scale)
           ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
           for mode in (S.BOUNDS_BVH, S.BOUNDS_OBB):
               gpu.upload_tree(buf, bounds=mode)
@@ -70,6 +79,7 @@ def run(seed, iters, gpu=None, log=print):
 
 
 if __name__ == "__main__":
-    n_bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+    n_bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 60,
+                heavy=len(sys.argv) > 3 and sys.argv[3] == "heavy")
     print("fuzz done, mismatches:", n_bad)
     sys.exit(1 if n_bad else 0)
