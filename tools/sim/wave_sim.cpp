@@ -56,11 +56,12 @@ struct Lane {
 
 struct Stats {
     uint64_t wave_steps = 0, wave_walks = 0, wave_inner = 0, wave_leaf = 0, lane_steps = 0, lane_walks = 0, lane_needed = 0,
-             lane_inner = 0, chain_inner = 0;
+             lane_inner = 0, chain_inner = 0, box_tests = 0, pushes = 0;
     uint64_t by_alive_steps[65] = {0}, by_alive_inner[65] = {0}, by_drive_walks[65] = {0}, by_drive_inner[65] = {0};
     void add(const Stats& o) {
         wave_steps += o.wave_steps; wave_walks += o.wave_walks; wave_inner += o.wave_inner; wave_leaf += o.wave_leaf;
         lane_steps += o.lane_steps; lane_walks += o.lane_walks; lane_needed += o.lane_needed; lane_inner += o.lane_inner; chain_inner += o.chain_inner;
+        box_tests += o.box_tests; pushes += o.pushes;
         for (int i = 0; i < 65; ++i) {
             by_alive_steps[i] += o.by_alive_steps[i]; by_alive_inner[i] += o.by_alive_inner[i];
             by_drive_walks[i] += o.by_drive_walks[i]; by_drive_inner[i] += o.by_drive_inner[i];
@@ -130,6 +131,7 @@ static void walk(Lane* L, Stats& st) {
             bool any0 = false, any1 = false;
             int n0 = 0, nt = 0;
             st.wave_inner++;
+            st.box_tests += 2;
             for (int i = 0; i < 64; ++i) {
                 const float sc = T.box_scale;   // box records are stored scaled (compact.cpp)
                 k0[i] = aabb_d2(N.c0, N.h0, L[i].px * sc, L[i].py * sc, L[i].pz * sc);
@@ -145,6 +147,7 @@ static void walk(Lane* L, Stats& st) {
             if (any0 && any1) {
                 chain = false;
                 bool first0 = 2 * n0 >= nt;
+                st.pushes++;
                 E& e = stk[sp++];
                 e.ref = first0 ? N.ref1 : N.ref0;
                 for (int i = 0; i < 64; ++i) e.k[i] = first0 ? k1[i] : k0[i];
@@ -204,6 +207,98 @@ static void walk(Lane* L, Stats& st) {
     st.by_drive_inner[ndrive] += st.wave_inner - inner0;
 }
 
+// SIM_WIDE: the same walk over four-wide nodes made by skipping every other level of the binary tree (a
+// visit tests the boxes of up to four grandchildren, descends into the one most lanes are nearest to and
+// pushes the other needed ones).  wave_inner counts wide visits (one dependent 128-byte fetch each).
+static int g_wide_policy = 1;   // SIM_WIDE=1: sorted by nearest-votes; 2: most-voted first, rest by index; 3: sorted by needing lanes
+static void walk_wide(Lane* L, Stats& st) {
+    uint32_t cur = T.root_ref;
+    if (cur == REF_NONE) return;
+    struct E { uint32_t ref; float k[64]; };
+    static thread_local std::vector<E> stk(256);
+    uint32_t sp = 0;
+    int ndrive = 0;
+    for (int i = 0; i < 64; ++i) {
+        ndrive += L[i].drive;
+        float bp = (std::fmax(L[i].best + L[i].mg, 0.f) + g_ext) * T.box_scale;
+        L[i].thr = bp * bp * 1.0006f;
+    }
+    uint64_t inner0 = st.wave_inner;
+    for (;;) {
+        while (!(cur & REF_LEAF)) {
+            const GpuInner& N = T.inner[cur];
+            const float* cc[4]; const float* hh[4]; uint32_t rr[4]; int nc = 0;
+            auto add_child = [&](uint32_t ref, const float* c, const float* h) {
+                if (ref & REF_LEAF) { cc[nc] = c; hh[nc] = h; rr[nc++] = ref; return; }
+                const GpuInner& M = T.inner[ref];
+                cc[nc] = M.c0; hh[nc] = M.h0; rr[nc++] = M.ref0;
+                cc[nc] = M.c1; hh[nc] = M.h1; rr[nc++] = M.ref1;
+            };
+            add_child(N.ref0, N.c0, N.h0);
+            add_child(N.ref1, N.c1, N.h1);
+            st.wave_inner++;
+            st.box_tests += nc;
+            float k[4][64]; bool any[4] = {false, false, false, false}; int votes[4] = {0, 0, 0, 0};
+            const float sc = T.box_scale;
+            for (int i = 0; i < 64; ++i) {
+                int bj = -1;
+                for (int j = 0; j < nc; ++j) {
+                    k[j][i] = aabb_d2(cc[j], hh[j], L[i].px * sc, L[i].py * sc, L[i].pz * sc);
+                    if (!L[i].drive) continue;
+                    if (k[j][i] <= L[i].thr) { any[j] = true; if (bj < 0 || k[j][i] < k[bj][i]) bj = j; }
+                }
+                if (!L[i].drive) continue;
+                st.lane_inner++;
+                if (bj >= 0) { votes[bj]++; st.lane_needed++; }
+                if (g_wide_policy == 3) { if (bj >= 0) votes[bj]--; for (int j = 0; j < nc; ++j) votes[j] += k[j][i] <= L[i].thr; }   // needing lanes
+            }
+            int order[4], no = 0;
+            for (int j = 0; j < nc; ++j) {
+                if (any[j]) order[no++] = j;
+                else for (int i = 0; i < 64; ++i) L[i].lbk = std::fmin(L[i].lbk, k[j][i]);
+            }
+            if (no == 0) { cur = REF_NONE; break; }
+            if (g_wide_policy == 2) {   // most-voted first, the others in index order
+                int bq = 0;
+                for (int q = 1; q < no; ++q) if (votes[order[q]] > votes[order[bq]]) bq = q;
+                std::rotate(order, order + bq, order + bq + 1);
+            } else std::stable_sort(order, order + no, [&](int a, int b) { return votes[a] > votes[b]; });
+            for (int q = no - 1; q >= 1; --q) {
+                st.pushes++;
+                E& e = stk[sp++];
+                e.ref = rr[order[q]];
+                for (int i = 0; i < 64; ++i) e.k[i] = k[order[q]][i];
+            }
+            cur = rr[order[0]];
+        }
+        if (cur != REF_NONE) {
+            uint32_t id = cur & REF_INDEX;
+            st.wave_leaf++;
+            for (int i = 0; i < 64; ++i) {
+                float d = leaf_eval(T.leaves[id], L[i].px, L[i].py, L[i].pz);
+                bool rival = id != L[i].bid;
+                bool b = rival && is_better(d, id, L[i].best, L[i].bid);
+                float loser = b ? L[i].best : d;
+                if (rival && loser < L[i].second) { L[i].second = loser; L[i].sid = b ? L[i].bid : id; }
+                if (b) { L[i].best = d; L[i].bid = id; }
+                float bp = (std::fmax(L[i].best + L[i].mg, 0.f) + g_ext) * T.box_scale;
+                L[i].thr = bp * bp * 1.0006f;
+            }
+        }
+        bool got = false;
+        while (sp > 0) {
+            E& e = stk[--sp];
+            bool anyl = false;
+            for (int i = 0; i < 64; ++i) anyl |= L[i].drive && e.k[i] <= L[i].thr;
+            if (anyl) { cur = e.ref; got = true; break; }
+            for (int i = 0; i < 64; ++i) L[i].lbk = std::fmin(L[i].lbk, e.k[i]);
+        }
+        if (!got) break;
+    }
+    st.by_drive_walks[ndrive]++;
+    st.by_drive_inner[ndrive] += st.wave_inner - inner0;
+}
+
 // One march step of a wave.  defer_thr > 0: lanes that cannot certify wait (do not advance) while fewer than
 // defer_thr of them are waiting and some certified lane can still advance.
 static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finished) {
@@ -248,7 +343,8 @@ static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finis
         if (!g_k2) for (int i = 0; i < 64; ++i) L[i].sid = SDF_NO_PRIM;
         st.wave_walks++;
         st.lane_walks += nunc;
-        walk(L, st);
+        static const bool wide = getenv("SIM_WIDE") != nullptr && (g_wide_policy = atoi(getenv("SIM_WIDE"))) > 0;
+        if (wide) walk_wide(L, st); else walk(L, st);
     }
     st.by_alive_inner[nalive] += st.wave_inner - inner0;
     for (int i = 0; i < 64; ++i) {
@@ -357,6 +453,7 @@ int main(int argc, char** argv) {
            st.wave_inner, st.wave_leaf, st.lane_steps, st.lane_walks);
     printf("inner/walk %.1f lane_inner/lane_walk %.1f needed/lane_walk %.1f  VALU est %.3fe9\n", (double)st.wave_inner / st.wave_walks,
            (double)st.lane_inner / st.lane_walks, (double)st.lane_needed / st.lane_walks, st.valu() / 1e9);
+    printf("box tests %lu (%.2f per node visit)  stack pushes %lu\n", st.box_tests, (double)st.box_tests / st.wave_inner, st.pushes);
     printf("leading single-child chain: %.2f inner visits per walk\n", (double)st.chain_inner / st.wave_walks);
     if (strat == "tile")
         for (int nr : {2, 4, 8}) {   // round-robin tile deal over nr ranks: heaviest rank against the mean
