@@ -58,7 +58,7 @@ typedef enum sdfgpu_layout {
 typedef enum sdfgpu_bounds {
     SDFGPU_BOUNDS_AUTO = 0,   /* BVH if the tree qualifies, else NONE */
     SDFGPU_BOUNDS_AABB = 1,   /* world AABBs recomputed bottom-up from the leaves at upload */
-    SDFGPU_BOUNDS_OBB = 2,    /* the buffer's own boxes: MINDIST of faux_shader.rs:54-58, with a margin */
+    SDFGPU_BOUNDS_OBB = 2,    /* the buffer's own boxes: MINDIST of faux_shader.rs:54-58 as the pruning bound, with a margin */
     SDFGPU_BOUNDS_NONE = 3,   /* no pruning: every primitive is evaluated (always valid) */
     SDFGPU_BOUNDS_BVH = 4     /* world AABBs over a hierarchy the library builds itself over the primitives
                                  (binned SAH); the buffer's topology only fixes the primitive order */

@@ -135,20 +135,21 @@ __device__ __forceinline__ float aabb_dist2(const float* __restrict__ c, const f
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-// MINDIST of faux_shader.rs:54-58 in the reference's own operation order
-// (rows of full_inverse, w lane dropped: it contributes exactly +0 when the
-// bottom row is (0,0,0,1) and scale.w == 0, which upload checks).
-__device__ __forceinline__ float obb_mindist(const float* __restrict__ fi, const float* __restrict__ sc, float px,
-                                             float py, float pz) {
-    float tx = ((fi[0] * px + fi[1] * py) + fi[2] * pz) + fi[3];
-    float ty = ((fi[4] * px + fi[5] * py) + fi[6] * pz) + fi[7];
-    float tz = ((fi[8] * px + fi[9] * py) + fi[10] * pz) + fi[11];
-    float qx = (__builtin_fabsf(tx) - 1.0f) * sc[0];
-    float qy = (__builtin_fabsf(ty) - 1.0f) * sc[1];
-    float qz = (__builtin_fabsf(tz) - 1.0f) * sc[2];
-    float mx = qx > 0.f ? qx : 0.f, my = qy > 0.f ? qy : 0.f, mz = qz > 0.f ? qz : 0.f;
-    float l = __builtin_sqrtf((mx * mx + mz * mz) + (my * my));   // glam SSE2 dot4 order, w term +0
-    return l + __builtin_fminf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.0f);
+// What the OBB walk prunes with: the SQUARE of MINDIST (faux_shader.rs:54-58: the point through
+// full_inverse, |t| - 1 scaled by the box's half extents, length of the positive part) where the point is
+// outside the box, 0 inside it.  A bound, not a result (the prune margin and the threshold's factor cover
+// its rounding), so it is formed with fused multiply-adds and without the square root: ~21 instructions
+// per box against ~55 for the value in the reference's own operation order, which box_bounds_kernel
+// still computes as written (a third of those 55 were the correctly rounded square root).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float obb_outside2(const f32x16& r, float px, float py, float pz) {   // r = fi[12], sc[3], ref
+    const float tx = __builtin_fmaf(r[0], px, __builtin_fmaf(r[1], py, __builtin_fmaf(r[2], pz, r[3])));
+    const float ty = __builtin_fmaf(r[4], px, __builtin_fmaf(r[5], py, __builtin_fmaf(r[6], pz, r[7])));
+    const float tz = __builtin_fmaf(r[8], px, __builtin_fmaf(r[9], py, __builtin_fmaf(r[10], pz, r[11])));
+    const float mx = __builtin_fmaxf((__builtin_fabsf(tx) - 1.0f) * r[12], 0.f);
+    const float my = __builtin_fmaxf((__builtin_fabsf(ty) - 1.0f) * r[13], 0.f);
+    const float mz = __builtin_fmaxf((__builtin_fabsf(tz) - 1.0f) * r[14], 0.f);
+    return __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
 }
 
 struct TreeView {
@@ -180,23 +181,20 @@ struct WaveCounters {
     uint32_t lane_sphere_needed = 0, lane_box_needed = 0;   // ... of which the lane's own bound asked for
 };
 
-// Prune threshold for the current best.  AABB mode compares squared
-// distances: a subtree is needed iff dist2(box) <= ((best + mg)^+)^2 * (1+6e-4);
-// OBB mode compares MINDIST directly: pruned iff m > 0 && m > best + mg
-// (the reference's test, faux_shader.rs:119-120, plus the margin).
+// Prune threshold for the current best.  Both kinds of box compare squared distances (0 inside the
+// box): a subtree is needed iff dist2(box) <= ((best + mg)^+)^2 * (1+6e-4).  For the OBB walk this is the
+// reference's test -- pruned iff m > 0 && m > best (faux_shader.rs:119-120) -- plus the margin, squared:
+// inside the box (m <= 0) the key is 0 and never above the threshold, and a negative best + mg (a point
+// inside a primitive) makes the threshold 0, so every box the point is outside of is pruned, as there.
 template <int MODE>
 __device__ __forceinline__ float prune_threshold(float best, float mg, float ext, float bscale) {
-    if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
-        return (best + mg) + ext;
-    } else {
-        float bp = (__builtin_fmaxf(best + mg, 0.f) + ext) * bscale;   // exact: bscale is a power of two
-        return bp * bp * 1.0006f;
-    }
+    float bp = __builtin_fmaxf(best + mg, 0.f) + ext;
+    if constexpr (MODE != SDFGPU_BOUNDS_OBB) bp *= bscale;   // exact: bscale is a power of two
+    return bp * bp * 1.0006f;
 }
 template <int MODE>
 __device__ __forceinline__ bool needed(float key, float thr) {
-    if constexpr (MODE == SDFGPU_BOUNDS_OBB) return !(key > 0.f && key > thr);
-    else return key <= thr;
+    return key <= thr;
 }
 
 // ---- accumulators: what a walk does with a primitive value / a skipped box ----
@@ -236,12 +234,23 @@ struct AccTracked {
 // One 64-byte record through the scalar cache: a single s_load_dwordx16 at
 // base + (idx << 6) (SGPR offset form: one shift instead of 64-bit pointer
 // arithmetic -- the CU's one scalar unit is the busiest pipe of the walk).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 load_rec64(const void* __restrict__ base, uint32_t idx) {
     f32x16 r;
     const uint32_t off = __builtin_amdgcn_readfirstlane(idx << 6);
     asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(off) : "memory");
     return r;
+}
+
+// The two 64-byte halves of one OBB node record (a child each), both requests in flight before the wait.
+// Left to the compiler, `T.inner_obb + cur` became eight 16-byte VECTOR loads per node -- all 64 lanes
+// fetching the same 128 bytes into 32 VGPRs each, which also held the kernel at 5 wavefronts per SIMD.
+__device__ __forceinline__ void load_rec128(const void* __restrict__ base, uint32_t idx, f32x16& a, f32x16& b) {
+    const uint32_t off = __builtin_amdgcn_readfirstlane(idx << 7);
+    const uint32_t off1 = off + 64u;
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b)
+                 : "s"(base), "s"(off), "s"(off1)
+                 : "memory");
 }
 
 // Bits of one float element of such a record as an integer.  A plain bit cast of
@@ -290,11 +299,12 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
         float k0, k1;
         uint32_t r0, r1;
         if constexpr (MODE == SDFGPU_BOUNDS_OBB) {
-            const GpuInnerObb* __restrict__ N = T.inner_obb + cur;
-            k0 = obb_mindist(N->fi0, N->sc0, px, py, pz);
-            k1 = obb_mindist(N->fi1, N->sc1, px, py, pz);
-            r0 = N->ref0;
-            r1 = N->ref1;
+            f32x16 A, B;   // child 0 / child 1: fi[12], sc[3], ref (GpuInnerObb)
+            load_rec128(T.inner_obb, cur, A, B);
+            k0 = obb_outside2(A, px, py, pz);
+            k1 = obb_outside2(B, px, py, pz);
+            r0 = rec_bits(A[15]);
+            r1 = rec_bits(B[15]);
         } else {
             const f32x16 N = load_rec64(T.inner, cur);
             const float c0[3] = {N[0], N[1], N[2]}, h0[3] = {N[3], N[4], N[5]};
@@ -958,7 +968,8 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
             best = acc.best;
             bid = acc.bid;
             // a bound, not a result: the hardware square root (1 ulp) is inside the 0.9996
-            float lb = (MODE == SDFGPU_BOUNDS_OBB) ? acc.lb_key : __builtin_amdgcn_sqrtf(acc.lb_key) * T.inv_bscale;
+            float lb = __builtin_amdgcn_sqrtf(acc.lb_key);
+            if constexpr (MODE != SDFGPU_BOUNDS_OBB) lb *= T.inv_bscale;
             lb = __builtin_fminf(lb * 0.9996f, acc.second) - mg;
             // only for the lanes the walk was for: a lane that has finished this pass's steps keeps the
             // budget it carries to the next pass (the walk saw the point it stopped at, not its next one)
