@@ -331,7 +331,8 @@ static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finis
     uint64_t inner0 = st.wave_inner;
     bool do_walk = nunc > 0;
     bool deferring = false;
-    if (defer_thr > 0 && nunc > 0 && nunc < defer_thr && ncert > 0) { do_walk = false; deferring = true; }
+    static const int min_cert = getenv("SIM_MINCERT") ? atoi(getenv("SIM_MINCERT")) : 1;   // walk early unless at least this many lanes can certify
+    if (defer_thr > 0 && nunc > 0 && nunc < defer_thr && ncert >= min_cert) { do_walk = false; deferring = true; }
     if (do_walk) {
         if (getenv("SIM_SEED2"))
             for (int i = 0; i < 64; ++i) {
