@@ -178,7 +178,16 @@ int sdfgpu_compact_host(const SdfOperationBlock* dt, const SdfOperationUptreeBlo
  * point.extend(1.0), node.rs:335,359).  out_dist[i] is the value the reference
  * returns; out_prim[i] is the pre-order ordinal of the primitive attaining it
  * (ties -> the later one, faux_shader.rs:27-29), SDF_NO_PRIM for an empty tree.
- * out_prim may be NULL. */
+ * out_prim may be NULL.
+ *
+ * Domain of a query point (every query entry point, k = 1 and kNN): each coordinate finite and at most
+ * 2^62 in magnitude.  A point outside it returns (NaN, SDF_NO_PRIM) in every slot, takes no part in
+ * the tree walk and has no effect on the other points of the batch.  (The reference has no defined
+ * result there: once a leaf value is NaN -- a NaN or infinite coordinate, inf - inf after an overflow --
+ * every `a < b` is false, its union keeps whichever operand came last and its prune test never fires.)
+ * Inside the domain results are the reference's, bit for bit; points further than ~1e4 scene extents
+ * from the scene are legal but slow: float32 no longer separates the primitives' distances there, so
+ * more and more of the tree has to be evaluated to resolve the (distance, later index) rule. */
 int sdfgpu_nearest(sdfgpu_ctx* ctx, const float* pts_xyzw, size_t n,
                    float* out_dist, uint32_t* out_prim);
 /* Device-pointer form; the w component is not read (taken as 1). */

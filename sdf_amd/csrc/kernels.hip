@@ -126,12 +126,24 @@ __device__ __forceinline__ float min_nn(float a, float b) { return a < b ? a : b
 // is then one subtraction with the hardware's [0,1] result clamp instead of a subtraction and a
 // max.  Scaling by a power of two is exact, so inside that range the test decides exactly what the
 // unscaled one would; beyond it the clamp only makes the bound smaller, i.e. prunes less.
+//
+// FAR.  A point further out than that must not use the clamp: every box would then look at most sqrt(3)
+// scaled units away while the search radius is larger, nothing would be pruned, and the walk would visit
+// the whole tree for its wavefront (a camera 20 scene extents away, a stray query point).  A walk with
+// such a driving lane (far_point, one ballot per walk) therefore runs the copy of the walk whose
+// per-axis distance is the plain max(|p - c| - h, 0): one more instruction per axis, same decisions
+// inside the range, real pruning outside it.
+constexpr float NEAR_LIMIT = 0.9375f;   // the scene lies within 1/16 (compact.cpp), so below this no per-axis distance reaches 1
+__device__ __forceinline__ bool far_point(float sx, float sy, float sz) {
+    return !(__builtin_fmaxf(__builtin_fabsf(sx), __builtin_fmaxf(__builtin_fabsf(sy), __builtin_fabsf(sz))) < NEAR_LIMIT);
+}
 __device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.f), 1.f); }
+template <bool FAR>
 __device__ __forceinline__ float aabb_dist2(const float* __restrict__ c, const float* __restrict__ h, float px,
                                             float py, float pz) {
-    float dx = clamp01(__builtin_fabsf(px - c[0]) - h[0]);
-    float dy = clamp01(__builtin_fabsf(py - c[1]) - h[1]);
-    float dz = clamp01(__builtin_fabsf(pz - c[2]) - h[2]);
+    float dx = __builtin_fabsf(px - c[0]) - h[0], dy = __builtin_fabsf(py - c[1]) - h[1], dz = __builtin_fabsf(pz - c[2]) - h[2];
+    if constexpr (FAR) { dx = __builtin_fmaxf(dx, 0.f); dy = __builtin_fmaxf(dy, 0.f); dz = __builtin_fmaxf(dz, 0.f); }
+    else { dx = clamp01(dx); dy = clamp01(dy); dz = clamp01(dz); }
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
@@ -292,6 +304,9 @@ __device__ __forceinline__ void nn_traverse_cxx(const TreeView& T, float px, flo
     if constexpr (COUNT) wc.lane_queries += mine ? 1u : 0u;
     cur = __builtin_amdgcn_readfirstlane(cur);
     float kcur = 0.f;   // COUNT: this lane's bound key of the node being visited (the root is always needed)
+    // a driving lane beyond the clamp's range: unclamped box distances for this walk (see aabb_dist2)
+    const bool far = MODE != SDFGPU_BOUNDS_OBB &&
+                     (__builtin_amdgcn_ballot_w64(far_point(px * T.bscale, py * T.bscale, pz * T.bscale)) & drive) != 0ull;
 
 top:   // single loop header (keeps the control flow reducible): cur is a valid reference
     if (cur & REF_LEAF) goto visit_leaf;
@@ -309,8 +324,13 @@ top:   // single loop header (keeps the control flow reducible): cur is a valid 
             const f32x16 N = load_rec64(T.inner, cur);
             const float c0[3] = {N[0], N[1], N[2]}, h0[3] = {N[3], N[4], N[5]};
             const float c1[3] = {N[6], N[7], N[8]}, h1[3] = {N[9], N[10], N[11]};
-            k0 = aabb_dist2(c0, h0, px * T.bscale, py * T.bscale, pz * T.bscale);
-            k1 = aabb_dist2(c1, h1, px * T.bscale, py * T.bscale, pz * T.bscale);
+            if (far) {
+                k0 = aabb_dist2<true>(c0, h0, px * T.bscale, py * T.bscale, pz * T.bscale);
+                k1 = aabb_dist2<true>(c1, h1, px * T.bscale, py * T.bscale, pz * T.bscale);
+            } else {
+                k0 = aabb_dist2<false>(c0, h0, px * T.bscale, py * T.bscale, pz * T.bscale);
+                k1 = aabb_dist2<false>(c1, h1, px * T.bscale, py * T.bscale, pz * T.bscale);
+            }
             r0 = rec_bits(N[12]);
             r1 = rec_bits(N[13]);
         }
@@ -401,7 +421,20 @@ pop:
 // other instructions, the two forms measured the same (frame 1.728 vs 1.735 ms).
 constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 
-#define SDFGPU_WALK_ASM(LBMIN_K0, LBMIN_K1, LBMIN_A, PREFETCH, CNT_INNER, CNT_LEAF)                                                   \
+// |a| - h, floored at 0, per axis: with the result clamp (near walk) or with an explicit max (far walk).
+#define SDFGPU_BOX_NEAR(H0, H1, H2)                                                                    \
+    "v_add_f32 %[a], -" H0 ", |%[a]| clamp\n\t"                                                        \
+    "v_add_f32 %[b], -" H1 ", |%[b]| clamp\n\t"                                                        \
+    "v_add_f32 %[c], -" H2 ", |%[c]| clamp\n\t"
+#define SDFGPU_BOX_FAR(H0, H1, H2)                                                                     \
+    "v_add_f32 %[a], -" H0 ", |%[a]|\n\t"                                                              \
+    "v_add_f32 %[b], -" H1 ", |%[b]|\n\t"                                                              \
+    "v_add_f32 %[c], -" H2 ", |%[c]|\n\t"                                                              \
+    "v_max_f32 %[a], 0, %[a]\n\t"                                                                     \
+    "v_max_f32 %[b], 0, %[b]\n\t"                                                                     \
+    "v_max_f32 %[c], 0, %[c]\n\t"
+
+#define SDFGPU_WALK_ASM(BOX, LBMIN_K0, LBMIN_K1, LBMIN_A, PREFETCH, CNT_INNER, CNT_LEAF)                                              \
     "s_cmp_eq_u32 %[cur], -2\n\t"                                                                      \
     "s_cbranch_scc1 .Lpop%=\n"                                                                         \
     ".Ltop%=:\n\t"                                                                                     \
@@ -415,18 +448,14 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
     "v_subrev_f32 %[a], s48, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s49, %[py]\n\t"                                                              \
     "v_subrev_f32 %[c], s50, %[pz]\n\t"                                                              \
-    "v_add_f32 %[a], -s51, |%[a]| clamp\n\t"                                                          \
-    "v_add_f32 %[b], -s52, |%[b]| clamp\n\t"                                                          \
-    "v_add_f32 %[c], -s53, |%[c]| clamp\n\t"                                                          \
+    BOX("s51", "s52", "s53")                                                                           \
     "v_mul_f32 %[k0], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k0], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k0], %[c], %[c]\n\t"                                                               \
     "v_subrev_f32 %[a], s54, %[px]\n\t"                                                              \
     "v_subrev_f32 %[b], s55, %[py]\n\t"                                                              \
     "v_subrev_f32 %[c], s56, %[pz]\n\t"                                                              \
-    "v_add_f32 %[a], -s57, |%[a]| clamp\n\t"                                                          \
-    "v_add_f32 %[b], -s58, |%[b]| clamp\n\t"                                                          \
-    "v_add_f32 %[c], -s59, |%[c]| clamp\n\t"                                                          \
+    BOX("s57", "s58", "s59")                                                                           \
     "v_mul_f32 %[k1], %[a], %[a]\n\t"                                                                \
     "v_fmac_f32 %[k1], %[b], %[b]\n\t"                                                               \
     "v_fmac_f32 %[k1], %[c], %[c]\n\t"                                                               \
@@ -515,7 +544,7 @@ constexpr uint32_t REF_POP = 0xFFFFFFFEu;
 
 // DBG: the block also counts the internal nodes and leaves it visits in two SGPRs (the instrumented
 // build behind SDFGPU_OPT_STATS_ASM_WALK; tests compare them with the C++ walk's counters).
-template <bool TRACK, bool DBG, bool PF>
+template <bool TRACK, bool DBG, bool PF, bool FAR>
 __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& refs, float& lb, float thr, float px,
                                              float py, float pz, unsigned long long drive, const GpuInner* base,
                                              const GpuLeaf* lbase, uint32_t sa, f32x16& rec, uint32_t& n_inner,
@@ -539,21 +568,24 @@ __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& r
     // so it cannot be listed as a clobber (-Winline-asm: "clobber list contains reserved registers: m0").
     // PF selects the copy with / without the scalar-cache prefetch (string literals cannot be chosen by a
     // template argument, hence the two branches per flavour).
-#define SDFGPU_WALK_FLAVOUR(PFTEXT)                                                                                   \
+#define SDFGPU_WALK_FLAVOUR(BOX, PFTEXT)                                                                              \
     if constexpr (DBG) {                                                                                              \
         static_assert(!TRACK, "the counting walk is instantiated for the query kernels only");                        \
-        asm volatile(SDFGPU_WALK_ASM("", "", "", PFTEXT, "s_add_u32 %[ni], %[ni], 1\n\t", "s_add_u32 %[nl], %[nl], 1\n\t") \
+        asm volatile(SDFGPU_WALK_ASM(BOX, "", "", "", PFTEXT, "s_add_u32 %[ni], %[ni], 1\n\t", "s_add_u32 %[nl], %[nl], 1\n\t") \
                      : SDFGPU_WALK_OUT, [ni] "+s"(n_inner), [nl] "+s"(n_leaf) : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);   \
     } else if constexpr (TRACK) {                                                                                     \
-        asm volatile(SDFGPU_WALK_ASM(SDFGPU_LB_K0, SDFGPU_LB_K1, SDFGPU_LB_A, PFTEXT, "", "")                         \
+        asm volatile(SDFGPU_WALK_ASM(BOX, SDFGPU_LB_K0, SDFGPU_LB_K1, SDFGPU_LB_A, PFTEXT, "", "")                    \
                      : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER);                                       \
     } else {                                                                                                          \
-        asm volatile(SDFGPU_WALK_ASM("", "", "", PFTEXT, "", "") : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER); \
+        asm volatile(SDFGPU_WALK_ASM(BOX, "", "", "", PFTEXT, "", "") : SDFGPU_WALK_OUT : SDFGPU_WALK_IN : SDFGPU_WALK_CLOBBER); \
     }
-    if constexpr (PF) {
-        SDFGPU_WALK_FLAVOUR(SDFGPU_WALK_PREFETCH)
+    if constexpr (FAR) {   // rare: one copy, without the prefetch
+        static_assert(!PF, "the far walk has no prefetching copy");
+        SDFGPU_WALK_FLAVOUR(SDFGPU_BOX_FAR, "")
+    } else if constexpr (PF) {
+        SDFGPU_WALK_FLAVOUR(SDFGPU_BOX_NEAR, SDFGPU_WALK_PREFETCH)
     } else {
-        SDFGPU_WALK_FLAVOUR("")
+        SDFGPU_WALK_FLAVOUR(SDFGPU_BOX_NEAR, "")
     }
 #undef SDFGPU_WALK_FLAVOUR
 #undef SDFGPU_WALK_OUT
@@ -561,7 +593,7 @@ __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& r
 #undef SDFGPU_WALK_CLOBBER
 }
 
-template <int MODE, bool DBG, bool PF, class Acc>
+template <int MODE, bool DBG, bool PF, bool FAR, class Acc>
 __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, float py, float pz,
                                                 unsigned long long drive, float ext, Acc& acc,
                                                 float* __restrict__ stk, uint32_t lane, WaveCounters& wc) {
@@ -579,7 +611,7 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
     uint32_t n_inner = 0, n_leaf = 0;   // DBG only
     for (;;) {
         f32x16 L;   // the leaf's record, fetched inside the block (undefined when the walk is over)
-        walk_advance<Acc::TRACKS, DBG, PF>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L, n_inner, n_leaf);
+        walk_advance<Acc::TRACKS, DBG, PF, FAR>(cur, sp, refs, lb, thr, sx, sy, sz, drive, T.inner, T.leaf, sa, L, n_inner, n_leaf);
         cur = __builtin_amdgcn_readfirstlane(cur);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (cur == REF_NONE) break;
@@ -603,8 +635,10 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
                                             float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
                                             WaveCounters& wc) {
     if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT == 1) nn_traverse_cxx<MODE, COUNT != 0>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else if (__builtin_amdgcn_readfirstlane(T.prefetch)) nn_traverse_asm<MODE, COUNT == 2, true>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else nn_traverse_asm<MODE, COUNT == 2, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else if ((__builtin_amdgcn_ballot_w64(far_point(px * T.bscale, py * T.bscale, pz * T.bscale)) & drive) != 0ull)
+        nn_traverse_asm<MODE, COUNT == 2, false, true>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else if (__builtin_amdgcn_readfirstlane(T.prefetch)) nn_traverse_asm<MODE, COUNT == 2, true, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else nn_traverse_asm<MODE, COUNT == 2, false, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
 }
 
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
@@ -632,6 +666,19 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
     }
 }
 
+// The domain of a query point: every coordinate finite and at most 2^62 in magnitude.  Outside it the
+// reference's own result is an accident: once a leaf value is NaN (a NaN or infinite coordinate, or
+// inf - inf after a product overflowed) every comparison with it is false, so `if a < b {a} else {b}`
+// (faux_shader.rs:27-29) keeps whatever came last and the prune test never fires; and where all values
+// overflow to +inf they all tie, which no walk can resolve without visiting every primitive.  Defined
+// instead (sdfgpu.h): such a point takes no part in the walk (it costs its wavefront nothing) and returns
+// (NaN, SDF_NO_PRIM) in every slot.  Below 2^62 no product of a coordinate with a matrix entry of a sane
+// scene overflows, so no leaf value is NaN.
+constexpr float DOMAIN_LIMIT = 4611686018427387904.0f;   // 2^62
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    return __builtin_fabsf(x) <= DOMAIN_LIMIT && __builtin_fabsf(y) <= DOMAIN_LIMIT && __builtin_fabsf(z) <= DOMAIN_LIMIT;   // false for NaN
+}
+
 // ----------------------------------------------------------- K1: nearest --
 // faux_shader::nearest_neighbor (faux_shader.rs:96-208) for n points, plus
 // the primitive index.  One point per lane.  `order` (optional) is a
@@ -654,9 +701,10 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     uint32_t bid = SDF_NO_PRIM;
     WaveCounters wc;
     AccNearest acc{best, bid};
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
-    best = acc.best;
-    bid = acc.bid;
+    const bool finite = finite3(p.x, p.y, p.z);
+    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && finite), 0.f, acc, stk, lane, wc);
+    best = finite ? acc.best : __builtin_nanf("");
+    bid = finite ? acc.bid : SDF_NO_PRIM;
     if (alive) {
         out_dist[src] = best;
         if (out_prim) out_prim[src] = bid;
@@ -691,6 +739,11 @@ struct AccK {
     unsigned long long key[K];
     __device__ __forceinline__ void init() {
         const unsigned long long pad = ((unsigned long long)ord_f32(__builtin_inff()) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+        for (int j = 0; j < K; ++j) key[j] = pad;
+    }
+    __device__ __forceinline__ void init_nan() {   // a non-finite query point: (NaN, SDF_NO_PRIM) in every slot
+        const unsigned long long pad = ((unsigned long long)ord_f32(__builtin_nanf("")) << 32) | 0xFFFFFFFFull;
 #pragma unroll
         for (int j = 0; j < K; ++j) key[j] = pad;
     }
@@ -734,7 +787,9 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     AccK<K> acc;
     acc.init();
     WaveCounters wc;
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive), 0.f, acc, stk, lane, wc);
+    const bool finite = finite3(p.x, p.y, p.z);
+    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && finite), 0.f, acc, stk, lane, wc);
+    if (!finite) acc.init_nan();
     if (alive) {
         // whole rows as 16-byte stores when the row is exactly K wide (rows are K * 4 bytes apart, so they
         // are aligned when the arrays are)
@@ -1317,27 +1372,29 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
     const bool alive = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[i];
+    const bool finite = finite3(p.x, p.y, p.z);   // see finite3: (NaN, SDF_NO_PRIM) otherwise, as on the pruned path
     if constexpr (K == 1) {
         if (eval_levels) {   // a combine that is not a plain minimum is in effect: the real post-order evaluation
             float d;
             uint32_t id;
             walk_eval(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, eval_stacks(gstk, eval_levels), lane, d, id);
             if (alive) {
-                out_dist[i] = d;
-                if (out_prim) out_prim[i] = id;
+                out_dist[i] = finite ? d : __builtin_nanf("");
+                if (out_prim) out_prim[i] = finite ? id : SDF_NO_PRIM;
             }
             return;
         }
         AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
         walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
-            out_dist[i] = acc.best;
-            if (out_prim) out_prim[i] = acc.bid;
+            out_dist[i] = finite ? acc.best : __builtin_nanf("");
+            if (out_prim) out_prim[i] = finite ? acc.bid : SDF_NO_PRIM;
         }
     } else {
         AccK<K> acc;
         acc.init();
         walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (!finite) acc.init_nan();
         if (alive) {
 #pragma unroll
             for (int j = 0; j < K; ++j)
