@@ -96,7 +96,12 @@ typedef struct sdfgpu_camera {
 
 /* Sphere-trace parameters.  The reference has no march loop; the
  * loop is defined in DESIGN.md and restated by oracle/oracle.cpp::oracle_render.
- * normal_h is the `h` of calcSphereNormal (src/main__.rs:152, 0.0001 there). */
+ * normal_h is the `h` of calcSphereNormal (src/main__.rs:152, 0.0001 there).
+ * Any parameter values are accepted (a step cap of 0, eps <= 0, t_max < t_min, a NaN far plane = none ...):
+ * the loop does what it says for them.  Domain of the march: a ray is a miss outright when a coordinate
+ * of the eye, or t_min, is beyond 2^60 in magnitude or not a number, or when its pixel has no direction
+ * (image-plane point = eye); a ray ends as a miss when t leaves min(t_max, 2^60) (or becomes NaN).  All
+ * points the loop evaluates are then inside the query domain below. */
 typedef struct sdfgpu_march_params {
     uint32_t max_steps;
     float eps_hit;

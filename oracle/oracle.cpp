@@ -618,12 +618,20 @@ int oracle_render(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut
             float l = len3(dir[0], dir[1], dir[2]);
             for (int c = 0; c < 3; ++c) dir[c] = dir[c] / l;
 
+            // Domain of the march (build-defined like the loop): the eye's coordinates and t_min
+            // within 2^60 and the direction finite, else the ray is a miss outright; t stays within
+            // min(t_max, 2^60), `!(t <= t_hi)` ending the ray for a NaN as well.  Every point the loop
+            // evaluates then has coordinates below 2^62, where no leaf value is NaN.
+            const float LIM = 1152921504606846976.0f;   // 2^60
+            bool ray_ok = std::fabs(mp->t_min) <= LIM;
+            for (int c = 0; c < 3; ++c) ray_ok = ray_ok && std::fabs(o[c]) <= LIM && std::fabs(dir[c]) <= LIM;   // false for NaN; |dir| <= 1 when finite
+            const float t_hi = std::fmin(mp->t_max, LIM);
             float tt = mp->t_min;
             uint8_t h = 0;
             uint32_t pid = SDF_NO_PRIM;
             uint32_t steps = 0;
             V4 p{0, 0, 0, 1};
-            for (uint32_t s = 0; s < mp->max_steps; ++s) {
+            for (uint32_t s = 0; ray_ok && s < mp->max_steps; ++s) {
                 p = V4{o[0] + dir[0] * tt, o[1] + dir[1] * tt, o[2] + dir[2] * tt, 1.0f};
                 DI r;
                 int e = nearest_one(t, p, mode, stack.data(), &r);
@@ -631,7 +639,7 @@ int oracle_render(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut
                 steps += 1;
                 if (r.d < mp->eps_hit) { h = 1; pid = r.id; break; }
                 tt = tt + r.d;
-                if (tt > mp->t_max) break;
+                if (!(tt <= t_hi)) break;
             }
             float nx = 0, ny = 0, nz = 0;
             if (h) {

@@ -679,6 +679,19 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
     return __builtin_fabsf(x) <= DOMAIN_LIMIT && __builtin_fabsf(y) <= DOMAIN_LIMIT && __builtin_fabsf(z) <= DOMAIN_LIMIT;   // false for NaN
 }
 
+// The march keeps its points inside that domain by construction (build-defined like the loop itself,
+// restated by oracle_render): a ray is a miss outright when a coordinate of the eye or t_min is beyond
+// 2^60 or not a number, or its direction is not finite (a pixel whose image-plane point is the eye), and
+// it ends as a miss when t leaves [.., min(t_max, 2^60)] -- `!(t <= t_hi)`, which also catches a NaN.
+// Then |p| <= |eye| + |t| < 2^62 at every step, so every nearest-primitive distance the loop adds is a
+// number, and a garbage camera costs nothing instead of a tree-wide walk per wavefront and step.
+constexpr float MARCH_LIMIT = 1152921504606846976.0f;   // 2^60
+__device__ __forceinline__ bool march_domain(float ex, float ey, float ez, float t_min) {
+    return __builtin_fabsf(ex) <= MARCH_LIMIT && __builtin_fabsf(ey) <= MARCH_LIMIT && __builtin_fabsf(ez) <= MARCH_LIMIT &&
+           __builtin_fabsf(t_min) <= MARCH_LIMIT;
+}
+__device__ __forceinline__ float march_t_hi(float t_max) { return __builtin_fminf(t_max, MARCH_LIMIT); }   // fmin: the limit when t_max is NaN
+
 // ----------------------------------------------------------- K1: nearest --
 // faux_shader::nearest_neighbor (faux_shader.rs:96-208) for n points, plus
 // the primitive index.  One point per lane.  `order` (optional) is a
@@ -864,6 +877,7 @@ __global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, floa
     const uint32_t lane = threadIdx.x & 63u;
     AccTracked acc{__builtin_inff(), SDF_NO_PRIM, __builtin_inff(), __builtin_inff()};
     WaveCounters wc;
+    if (!march_domain(ex, ey, ez, 0.f)) return;   // no ray of such a frame marches (march_domain): nobody reads *out
     nn_traverse<MODE, 0>(T, ex, ey, ez, ~0ull, T.skip_ext, acc, smem, lane, wc);
     if (lane == 0) *out = make_float4(acc.best, __builtin_bit_cast(float, acc.bid), acc.lb_key, acc.second);
 }
@@ -938,6 +952,8 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     dx = dx / dl;
     dy = dy / dl;
     dz = dz / dl;
+    alive = alive && finite3(dx, dy, dz) && march_domain(ox, oy, oz, mp.t_min);   // otherwise a miss outright (march_domain)
+    const float t_hi = march_t_hi(mp.t_max);
 
     float px = 0.f, py = 0.f, pz = 0.f;
     // `budget`: proven lower bound, at the current point, on the distance of every
@@ -1046,7 +1062,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         budget = go ? bn : budget;
         last = adv ? bid : last;
         s += adv ? 1u : 0u;
-        state = hit_now ? 1u : ((go & (tn > mp.t_max)) ? 2u : state);
+        state = hit_now ? 1u : ((go & !(tn <= t_hi)) ? 2u : state);
         eye_step = false;   // only the very first iteration of a ray's march can stand at the eye
         if (!cheap) {   // the walk may have changed `last`: fetch its record once
             if ((state == 0u) & (s < pa.step_end) & (last != SDF_NO_PRIM)) {   // (an empty tree has no nearest primitive)
@@ -1428,7 +1444,8 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
     const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
     dx = dx / dl; dy = dy / dl; dz = dz / dl;
     float t = mp.t_min;
-    bool alive = inside, hit = false;
+    bool alive = inside && finite3(dx, dy, dz) && march_domain(ox, oy, oz, mp.t_min), hit = false;
+    const float t_hi = march_t_hi(mp.t_max);
     uint32_t hit_prim = SDF_NO_PRIM;
     float px = 0.f, py = 0.f, pz = 0.f;
     for (uint32_t s = 0; s < mp.max_steps; ++s) {
@@ -1439,7 +1456,7 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
         else walk_general(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
             if (acc.best < mp.eps_hit) { hit = true; hit_prim = acc.bid; alive = false; }
-            else { t = t + acc.best; if (t > mp.t_max) alive = false; }
+            else { t = t + acc.best; if (!(t <= t_hi)) alive = false; }
         }
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
