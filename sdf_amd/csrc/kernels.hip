@@ -134,8 +134,10 @@ __device__ __forceinline__ float min_nn(float a, float b) { return a < b ? a : b
 // per-axis distance is the plain max(|p - c| - h, 0): one more instruction per axis, same decisions
 // inside the range, real pruning outside it.
 constexpr float NEAR_LIMIT = 0.9375f;   // the scene lies within 1/16 (compact.cpp), so below this no per-axis distance reaches 1
-__device__ __forceinline__ bool far_point(float sx, float sy, float sz) {
-    return !(__builtin_fmaxf(__builtin_fabsf(sx), __builtin_fmaxf(__builtin_fabsf(sy), __builtin_fabsf(sz))) < NEAR_LIMIT);
+// The test is on |x| + |y| + |z| (>= the largest coordinate, so it errs towards the far walk, which is
+// correct everywhere): that sum is already formed for the prune margin, so the test costs one compare.
+__device__ __forceinline__ bool far_point(float px, float py, float pz, float inv_bscale) {
+    return !((__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz)) < NEAR_LIMIT * inv_bscale);
 }
 __device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.f), 1.f); }
 template <bool FAR>
@@ -306,7 +308,7 @@ __device__ __forceinline__ void nn_traverse_cxx(const TreeView& T, float px, flo
     float kcur = 0.f;   // COUNT: this lane's bound key of the node being visited (the root is always needed)
     // a driving lane beyond the clamp's range: unclamped box distances for this walk (see aabb_dist2)
     const bool far = MODE != SDFGPU_BOUNDS_OBB &&
-                     (__builtin_amdgcn_ballot_w64(far_point(px * T.bscale, py * T.bscale, pz * T.bscale)) & drive) != 0ull;
+                     (__builtin_amdgcn_ballot_w64(far_point(px, py, pz, T.inv_bscale)) & drive) != 0ull;
 
 top:   // single loop header (keeps the control flow reducible): cur is a valid reference
     if (cur & REF_LEAF) goto visit_leaf;
@@ -630,12 +632,16 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
 
 // COUNT: 0 = production, 1 = the C++ state machine with every counter, 2 = the assembly walk with its
 // wave-level visit counters (query kernels only; what SDFGPU_OPT_STATS_ASM_WALK selects).
-template <int MODE, int COUNT, class Acc>
+// FARCHK false: the caller knows that no point it will ever pass is outside the near range (a march whose
+// eye and far plane are both well inside it: launch_render_m decides on the host), so that kernel carries
+// neither the per-walk test nor the far copy -- which in the march's loop cost 1.2 % of the frame, and four
+// more SGPRs for a flag instead cost it its eighth wavefront per SIMD (9 %).
+template <int MODE, int COUNT, bool FARCHK = true, class Acc>
 __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, unsigned long long drive,
                                             float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
                                             WaveCounters& wc) {
     if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT == 1) nn_traverse_cxx<MODE, COUNT != 0>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else if ((__builtin_amdgcn_ballot_w64(far_point(px * T.bscale, py * T.bscale, pz * T.bscale)) & drive) != 0ull)
+    else if (FARCHK && (__builtin_amdgcn_ballot_w64(far_point(px, py, pz, T.inv_bscale)) & drive) != 0ull)
         nn_traverse_asm<MODE, COUNT == 2, false, true>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
     else if (__builtin_amdgcn_readfirstlane(T.prefetch)) nn_traverse_asm<MODE, COUNT == 2, true, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
     else nn_traverse_asm<MODE, COUNT == 2, false, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, floa
     if (lane == 0) *out = make_float4(acc.best, __builtin_bit_cast(float, acc.bid), acc.lb_key, acc.second);
 }
 
-template <int MODE, bool COUNT, bool FIRST>
+template <int MODE, bool COUNT, bool FIRST, bool FAR>
 __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_camera cam, uint32_t width, uint32_t height,
                                                           sdfgpu_march_params mp, uint32_t tile_first,
                                                           uint32_t tile_stride, uint32_t tile_count, uint32_t row_major,
@@ -1034,7 +1040,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
                 acc.second = e.w;
             } else {
                 if constexpr (COUNT) wc.wave_walks += 1;
-                nn_traverse<MODE, COUNT>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
+                nn_traverse<MODE, COUNT, FAR>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
             }
             best = acc.best;
             bid = acc.bid;
@@ -1648,6 +1654,12 @@ static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam,
     const uint32_t wpg = wg_waves();
     dim3 grid((tile_count + wpg - 1u) / wpg), block(64u * wpg);
     const size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
+    // Can a point of this march lie outside the near range of the scaled box test (aabb_dist2)?  Each
+    // coordinate of o + d t is within |o_a| + |t| of 0 (|d| = 1), t between t_min and min(t_max, 2^60), with
+    // 2 % to spare for rounding.  If not -- any ordinary camera -- the kernel without the far walk runs.
+    const float reach = std::fmax(std::fabs(cam.eye[0]), std::fmax(std::fabs(cam.eye[1]), std::fabs(cam.eye[2]))) +
+                        std::fmax(std::fabs(mp.t_min), std::fabs(std::fmin(mp.t_max, MARCH_LIMIT)));
+    const bool far = MODE != SDFGPU_BOUNDS_OBB && !(reach * 1.02f < NEAR_LIMIT * v.inv_bscale);   // true for a NaN as well
     // pass boundaries: 0 = b[0] < b[1] < ... < b[n-1] = max_steps
     for (uint32_t k = 0; k + 1 < n_bounds; ++k) {
         PassArgs pa;
@@ -1669,12 +1681,12 @@ static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam,
             if (e != hipSuccess) return e;
             pa.eye = (const float4*)rs.eye;
         }
-        if (k == 0)
-            render_pass_kernel<MODE, COUNT, true><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
-                                                                          row_major ? 1u : 0u, pa, hit, depth, normal, prim, st);
-        else
-            render_pass_kernel<MODE, COUNT, false><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count,
-                                                                           row_major ? 1u : 0u, pa, hit, depth, normal, prim, st);
+#define SDFGPU_PASS(FIRST, FAR)                                                                                               \
+    render_pass_kernel<MODE, COUNT, FIRST, FAR><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count, \
+                                                                        row_major ? 1u : 0u, pa, hit, depth, normal, prim, st)
+        if (k == 0) { if (far) SDFGPU_PASS(true, true); else SDFGPU_PASS(true, false); }
+        else { if (far) SDFGPU_PASS(false, true); else SDFGPU_PASS(false, false); }
+#undef SDFGPU_PASS
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (!pa.final_pass) {
