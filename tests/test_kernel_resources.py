@@ -1,0 +1,74 @@
+"""Register budgets of the walking kernels, from the compiler's own resource report (hipcc cross-compiles
+gfx950 without a GPU): the production kernels must stay at 8 wavefronts per SIMD.
+
+gfx950 allocates SGPRs in blocks of 16 out of 800 per SIMD and VGPRs out of 512: 8 resident wavefronts need
+at most 96 SGPRs and 64 VGPRs.  The march kernel sits at 93 SGPRs, and a change as small as one more
+wave-uniform flag held across its loop has pushed it to 97 = 7 wavefronts = 9 % of the frame (DESIGN.md
+section 3, "Far walk"); the compiler's "Occupancy" line does not show that (it reported 8).  No kernel may
+spill to scratch memory."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sdf_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def report(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("asm") / "kernels.s"
+    flags = subprocess.run(["make", "-s", "-C", CSRC, "print-hipflags"], capture_output=True, text=True)
+    assert flags.returncode == 0, flags.stderr
+    cmd = [HIPCC] + flags.stdout.split() + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                                             os.path.join(CSRC, "kernels.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    assert len(kernels) > 30
+    return kernels
+
+
+def _pick(kernels, *parts):
+    got = {k: v for k, v in kernels.items() if all(p in k for p in parts)}
+    assert got, parts
+    return got
+
+
+def test_no_kernel_spills(report):
+    spilled = {k: v["ScratchSize"] for k, v in report.items() if v.get("ScratchSize", 0) != 0}
+    assert not spilled, spilled
+
+
+@pytest.mark.parametrize("parts", [
+    ("render_pass_kernelILi1ELb0E",),           # the march, BVH / AABB boxes, every (first pass, far) version
+    ("nearest_kernelILi1ELi0E",),               # k = 1 query
+    ("knn_kernelILi1ELi8ELb0E",),               # k = 8 query
+    ("knn_kernelILi1ELi4ELb0E",),
+    ("knn_kernelILi1ELi2ELb0E",),
+    ("eye_walk_kernelILi1E",),
+])
+def test_production_kernels_keep_eight_wavefronts(report, parts):
+    for name, r in _pick(report, *parts).items():
+        assert r["TotalSGPRs"] <= 96, (name, r)
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 64, (name, r)
+        assert r["Occupancy"] == 8, (name, r)
+
+
+def test_obb_march_keeps_seven_wavefronts(report):
+    # the OBB walk holds both children's 64-byte records in SGPRs (load_rec128): 7 wavefronts, not fewer
+    for name, r in _pick(report, "render_pass_kernelILi2ELb0E").items():
+        assert r["TotalSGPRs"] <= 112 and r["VGPRs"] <= 72, (name, r)
