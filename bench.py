@@ -282,7 +282,7 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
     return out
 
 
-def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true>"):
+def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true, false>"):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE are collected in separate runs by tools/profile_bench.sh;
     bench.py itself cannot read counters).  FETCH_SIZE/WRITE_SIZE are in KiB; the reads of
@@ -637,7 +637,7 @@ def main():
             bytes_alg = npix * 21 + int(info.device_bytes)
             traffic, traffic_note = profiled_traffic()
             line["roofline"] = roofline_object(
-                st, k_avg, "sdfgpu::render_pass_kernel<1, false, true>", bytes_alg,
+                st, k_avg, "sdfgpu::render_pass_kernel<1, false, true, false>", bytes_alg,
                 note="fp32 VALU-bound tree walk, no dense contraction (no MFMA); kernel_ms_avg = isolated launches under "
                      "HIP events on the launch stream, outside the timed region",
                 traffic=traffic, traffic_note=traffic_note)

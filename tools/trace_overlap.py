@@ -12,7 +12,7 @@ def main(src, dst):
     rows = []
     with open(src) as f:
         for r in csv.DictReader(f):
-            if "render_pass_kernel<1, false, true>" in r["Kernel_Name"]:
+            if "render_pass_kernel<1, false, true" in r["Kernel_Name"]:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r.get("Stream_Id", "")))
     rows.sort()
     t0 = rows[0][0]
