@@ -179,6 +179,7 @@ struct TreeView {
     float bscale;       // AABB modes: power-of-two scale of the boxes (point and threshold are scaled to match)
     float lip;          // max change of any leaf value per unit the point moves, rounded up (1.000004 for rigid leaves)
     uint32_t prefetch;  // 1: the walk warms the scalar cache with both children's records (trees beyond one XCD's L2)
+    uint32_t xcd;       // query kernels: each XCD works through a contiguous range of the batch (xcd_block; SDFGPU_XCD_ORDER=0 turns it off)
 };
 
 // Absolute slack covering the rounding of a leaf value at point p (DESIGN.md "pruning").
@@ -698,6 +699,16 @@ __device__ __forceinline__ bool march_domain(float ex, float ey, float ez, float
 }
 __device__ __forceinline__ float march_t_hi(float t_max) { return __builtin_fminf(t_max, MARCH_LIMIT); }   // fmin: the limit when t_max is NaN
 
+// Workgroups go to the 8 XCDs round-robin (block b runs on XCD b % 8).  Remapped, XCD x works through the
+// contiguous range of the (spatially ordered) batch that starts at x * nb / 8, so that its L2 sees one
+// moving neighbourhood of the tree instead of an eighth of all of them.  10 M points against the 12.8 MB
+// tree: k = 8 1.756 -> 1.713 ms per batch, k = 1 1.136 -> 1.102, caller-sorted k = 1 0.430 -> 0.380.  (At
+// 7 wavefronts per SIMD and the round's earlier, slower walk the same remap had measured as a loss.)
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, l = b >> 3;
+    return x * q + (x < r ? x : r) + l;
+}
+
 // ----------------------------------------------------------- K1: nearest --
 // faux_shader::nearest_neighbor (faux_shader.rs:96-208) for n points, plus
 // the primitive index.  One point per lane.  `order` (optional) is a
@@ -711,7 +722,8 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* stk = smem + wave * T.depth * 64u;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t blk = T.xcd ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t slot = blk * blockDim.x + threadIdx.x;
     const bool alive = slot < n;
     const uint32_t src = alive ? (order ? order[slot] : slot) : 0u;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
@@ -798,7 +810,8 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* __restrict__ stk = smem + wave * T.depth * 64u;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t blk = T.xcd ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t slot = blk * blockDim.x + threadIdx.x;
     const bool alive = slot < n;
     const uint32_t src = alive ? (order ? order[slot] : slot) : 0u;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
@@ -1545,7 +1558,13 @@ static uint32_t wg_waves() {
     return v;
 }
 
-static TreeView make_view(const DeviceTree& d) {
+// prefetch_beyond: size of the record arrays from which the walk warms the scalar cache with both children
+// (SDFGPU_PREFETCH=0/1 overrides, for measurements).  Measured with 10 M points per batch on trees of
+// 12 / 49 / 195 MiB (tools/query_sweep.py): k = 8 gains 3 / 8 / 10 % from it, the march on the 4K frame
+// likewise; k = 1, with a third as many primitives evaluated per walk, loses 2-3 % on the 12 MiB tree and
+// gains 0-8 % on the larger ones -- so one XCD's L2 (4 MiB) is the limit for every kernel but the k = 1
+// query, whose limit is 32 MiB.
+static TreeView make_view(const DeviceTree& d, size_t prefetch_beyond = 4u << 20) {
     TreeView v;
     v.leaf = d.leaf;
     v.inner = d.inner;
@@ -1558,9 +1577,10 @@ static TreeView make_view(const DeviceTree& d) {
     v.lip = d.lipschitz;
     v.bscale = d.box_scale;
     v.inv_bscale = 1.0f / d.box_scale;
-    // both record arrays together beyond one XCD's 4 MB L2 (SDFGPU_PREFETCH=0/1 overrides, for measurements)
     static const int forced = [] { const char* e = std::getenv("SDFGPU_PREFETCH"); return e ? std::atoi(e) : -1; }();
-    v.prefetch = forced >= 0 ? (uint32_t)(forced != 0) : (uint32_t)((size_t)d.n_leaf * (sizeof(GpuLeaf) + sizeof(GpuInner)) > (4u << 20));
+    static const int xcd = [] { const char* e = std::getenv("SDFGPU_XCD_ORDER"); return e ? std::atoi(e) : 1; }();
+    v.xcd = (uint32_t)(xcd != 0);
+    v.prefetch = forced >= 0 ? (uint32_t)(forced != 0) : (uint32_t)((size_t)d.n_leaf * (sizeof(GpuLeaf) + sizeof(GpuInner)) > prefetch_beyond);
     return v;
 }
 
@@ -1568,7 +1588,7 @@ template <int COUNT>
 static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n,
                                    float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    TreeView v = make_view(d);
+    TreeView v = make_view(d, 32u << 20);
     const uint32_t wpg = wg_waves();
     dim3 grid((n + 64u * wpg - 1u) / (64u * wpg)), block(64u * wpg);
     size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
