@@ -699,14 +699,18 @@ __device__ __forceinline__ bool march_domain(float ex, float ey, float ez, float
 }
 __device__ __forceinline__ float march_t_hi(float t_max) { return __builtin_fminf(t_max, MARCH_LIMIT); }   // fmin: the limit when t_max is NaN
 
-// Workgroups go to the 8 XCDs round-robin (block b runs on XCD b % 8).  Remapped, XCD x works through the
-// contiguous range of the (spatially ordered) batch that starts at x * nb / 8, so that its L2 sees one
-// moving neighbourhood of the tree instead of an eighth of all of them.  10 M points against the 12.8 MB
-// tree: k = 8 1.756 -> 1.713 ms per batch, k = 1 1.136 -> 1.102, caller-sorted k = 1 0.430 -> 0.380.  (At
-// 7 wavefronts per SIMD and the round's earlier, slower walk the same remap had measured as a loss.)
-__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
-    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, l = b >> 3;
-    return x * q + (x < r ? x : r) + l;
+// Workgroups go to the 8 XCDs round-robin (block b runs on XCD b % 8), so consecutive blocks of a spatially
+// ordered batch used to land on eight different L2s, each of which saw an eighth of every neighbourhood of
+// the tree.  Remapped, an XCD works through chunks of consecutive blocks, the chunks dealt round-robin (so a
+// dear region of a skewed batch is shared by all XCDs): one slowly moving neighbourhood per L2.  10 M points
+// against the 12.8 MB tree: k = 8 1.756 -> 1.65-1.69 ms per batch, k = 1 1.136 -> 1.08, caller-sorted k = 1
+// 0.430 -> 0.37.  (At 7 wavefronts per SIMD and the round's earlier, slower walk a remap had measured as a
+// loss: the record fetches were not yet what the kernel waited for.)
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
+    // chunks of `chunk` consecutive blocks dealt round-robin: XCD x takes chunks x, x + 8, ...  (the grid is
+    // padded to a multiple of 8 * chunk blocks, query_grid; a block beyond the batch finds no point and exits)
+    const uint32_t x = b & 7u, l = b >> 3;
+    return ((l / chunk) * 8u + x) * chunk + l % chunk;
 }
 
 // ----------------------------------------------------------- K1: nearest --
@@ -722,9 +726,10 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* stk = smem + wave * T.depth * 64u;
-    const uint32_t blk = T.xcd ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t blk = T.xcd ? xcd_block(blockIdx.x, T.xcd) : blockIdx.x;
     const uint32_t slot = blk * blockDim.x + threadIdx.x;
     const bool alive = slot < n;
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;   // a wavefront of the grid's padding (query_grid)
     const uint32_t src = alive ? (order ? order[slot] : slot) : 0u;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[src];
@@ -810,9 +815,10 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* __restrict__ stk = smem + wave * T.depth * 64u;
-    const uint32_t blk = T.xcd ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t blk = T.xcd ? xcd_block(blockIdx.x, T.xcd) : blockIdx.x;
     const uint32_t slot = blk * blockDim.x + threadIdx.x;
     const bool alive = slot < n;
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;   // a wavefront of the grid's padding (query_grid)
     const uint32_t src = alive ? (order ? order[slot] : slot) : 0u;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[src];
@@ -1578,10 +1584,20 @@ static TreeView make_view(const DeviceTree& d, size_t prefetch_beyond = 4u << 20
     v.bscale = d.box_scale;
     v.inv_bscale = 1.0f / d.box_scale;
     static const int forced = [] { const char* e = std::getenv("SDFGPU_PREFETCH"); return e ? std::atoi(e) : -1; }();
-    static const int xcd = [] { const char* e = std::getenv("SDFGPU_XCD_ORDER"); return e ? std::atoi(e) : 1; }();
-    v.xcd = (uint32_t)(xcd != 0);
+    v.xcd = 0;   // set by query_grid for the query kernels
     v.prefetch = forced >= 0 ? (uint32_t)(forced != 0) : (uint32_t)((size_t)d.n_leaf * (sizeof(GpuLeaf) + sizeof(GpuInner)) > prefetch_beyond);
     return v;
+}
+
+// Grid of a query kernel over nb blocks, and the chunk size of its XCD-aware block order (TreeView::xcd, 0 =
+// plain order): 1/32 of the batch, at most 1024 blocks (SDFGPU_XCD_ORDER: 0 = off, n = that chunk size).
+static uint32_t query_grid(uint32_t nb, TreeView* v) {
+    static const int env = [] { const char* e = std::getenv("SDFGPU_XCD_ORDER"); return e ? std::atoi(e) : -1; }();
+    uint32_t chunk = env >= 0 ? (uint32_t)env : std::min(1024u, nb / 32u);
+    if (chunk == 0 || nb < 64u) { v->xcd = 0; return nb; }
+    v->xcd = chunk;
+    const uint32_t group = 8u * chunk;
+    return (nb + group - 1u) / group * group;
 }
 
 template <int COUNT>
@@ -1590,7 +1606,7 @@ static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const 
     if (n == 0) return hipSuccess;
     TreeView v = make_view(d, 32u << 20);
     const uint32_t wpg = wg_waves();
-    dim3 grid((n + 64u * wpg - 1u) / (64u * wpg)), block(64u * wpg);
+    dim3 grid(query_grid((n + 64u * wpg - 1u) / (64u * wpg), &v)), block(64u * wpg);
     size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
     if (d.bounds == SDFGPU_BOUNDS_OBB)
         nearest_kernel<SDFGPU_BOUNDS_OBB, COUNT><<<grid, block, lds, s>>>(v, (const float4*)pts, order, n, out_dist, out_prim, st);
@@ -1634,7 +1650,7 @@ static hipError_t launch_knn_m(const DeviceTree& d, const float* pts, const uint
                                float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     TreeView v = make_view(d);
     const uint32_t wpg = wg_waves();
-    dim3 grid((n + 64u * wpg - 1u) / (64u * wpg)), block(64u * wpg);
+    dim3 grid(query_grid((n + 64u * wpg - 1u) / (64u * wpg), &v)), block(64u * wpg);
     size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
     const float4* p4 = (const float4*)pts;
     if (k <= 2) knn_kernel<MODE, 2, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);

@@ -21,6 +21,10 @@ L = S.default_extent(n_prims)
 rng = np.random.default_rng(5)
 pts = np.ones((n, 4), np.float32)
 pts[:, :3] = rng.uniform(-1.1 * L, 1.1 * L, (n, 3)).astype(np.float32)
+far = float(os.environ.get("SWEEP_FAR_FRACTION", "0"))
+if far > 0:   # a skewed batch: that share of the points 20-30 extents out in one direction (several times the cost per point)
+    m = int(n * far)
+    pts[:m, :3] = (np.array([25.0 * L, 0.0, 0.0]) + rng.uniform(-5 * L, 5 * L, (m, 3))).astype(np.float32)
 dev = torch.device("cuda", 0)
 
 
@@ -41,7 +45,7 @@ def run(p, k, reorder):
 
 t = torch.from_numpy(pts).to(dev)
 res = {"unsorted k1": run(t, 1, True), "unsorted k8": run(t, 8, True)}
-ts = torch.from_numpy(pts[np.argsort(W.hilbert_keys(pts[:, :3], 1.1 * L), kind="stable")]).to(dev)
+ts = torch.from_numpy(pts[np.argsort(W.hilbert_keys(pts[:, :3], float(np.abs(pts[:, :3]).max())), kind="stable")]).to(dev)
 res["sorted k1"] = run(ts, 1, False)
 res["sorted k8"] = run(ts, 8, False)
 print(f"{n_prims} prims, tree {info.device_bytes / 2**20:.1f} MiB, prefetch env {os.environ.get('SDFGPU_PREFETCH', 'auto')}, xcd env {os.environ.get('SDFGPU_XCD_ORDER', 'default')}: "
