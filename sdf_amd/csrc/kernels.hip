@@ -682,7 +682,7 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
 // (NaN, SDF_NO_PRIM) in every slot.  Below 2^62 no product of a coordinate with a matrix entry of a sane
 // scene overflows, so no leaf value is NaN.
 constexpr float DOMAIN_LIMIT = 4611686018427387904.0f;   // 2^62
-__device__ __forceinline__ bool finite3(float x, float y, float z) {
+__device__ __forceinline__ bool in_domain3(float x, float y, float z) {
     return __builtin_fabsf(x) <= DOMAIN_LIMIT && __builtin_fabsf(y) <= DOMAIN_LIMIT && __builtin_fabsf(z) <= DOMAIN_LIMIT;   // false for NaN
 }
 
@@ -737,10 +737,10 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     uint32_t bid = SDF_NO_PRIM;
     WaveCounters wc;
     AccNearest acc{best, bid};
-    const bool finite = finite3(p.x, p.y, p.z);
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && finite), 0.f, acc, stk, lane, wc);
-    best = finite ? acc.best : __builtin_nanf("");
-    bid = finite ? acc.bid : SDF_NO_PRIM;
+    const bool in_dom = in_domain3(p.x, p.y, p.z);
+    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
+    best = in_dom ? acc.best : __builtin_nanf("");
+    bid = in_dom ? acc.bid : SDF_NO_PRIM;
     if (alive) {
         out_dist[src] = best;
         if (out_prim) out_prim[src] = bid;
@@ -825,9 +825,9 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     AccK<K> acc;
     acc.init();
     WaveCounters wc;
-    const bool finite = finite3(p.x, p.y, p.z);
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && finite), 0.f, acc, stk, lane, wc);
-    if (!finite) acc.init_nan();
+    const bool in_dom = in_domain3(p.x, p.y, p.z);
+    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
+    if (!in_dom) acc.init_nan();
     if (alive) {
         // whole rows as 16-byte stores when the row is exactly K wide (rows are K * 4 bytes apart, so they
         // are aligned when the arrays are)
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     dx = dx / dl;
     dy = dy / dl;
     dz = dz / dl;
-    alive = alive && finite3(dx, dy, dz) && march_domain(ox, oy, oz, mp.t_min);   // otherwise a miss outright (march_domain)
+    alive = alive && in_domain3(dx, dy, dz) && march_domain(ox, oy, oz, mp.t_min);   // otherwise a miss outright (march_domain)
     const float t_hi = march_t_hi(mp.t_max);
 
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -1413,29 +1413,29 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
     const bool alive = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[i];
-    const bool finite = finite3(p.x, p.y, p.z);   // see finite3: (NaN, SDF_NO_PRIM) otherwise, as on the pruned path
+    const bool in_dom = in_domain3(p.x, p.y, p.z);   // see in_domain3: (NaN, SDF_NO_PRIM) otherwise, as on the pruned path
     if constexpr (K == 1) {
         if (eval_levels) {   // a combine that is not a plain minimum is in effect: the real post-order evaluation
             float d;
             uint32_t id;
             walk_eval(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, eval_stacks(gstk, eval_levels), lane, d, id);
             if (alive) {
-                out_dist[i] = finite ? d : __builtin_nanf("");
-                if (out_prim) out_prim[i] = finite ? id : SDF_NO_PRIM;
+                out_dist[i] = in_dom ? d : __builtin_nanf("");
+                if (out_prim) out_prim[i] = in_dom ? id : SDF_NO_PRIM;
             }
             return;
         }
         AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
         walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
-            out_dist[i] = finite ? acc.best : __builtin_nanf("");
-            if (out_prim) out_prim[i] = finite ? acc.bid : SDF_NO_PRIM;
+            out_dist[i] = in_dom ? acc.best : __builtin_nanf("");
+            if (out_prim) out_prim[i] = in_dom ? acc.bid : SDF_NO_PRIM;
         }
     } else {
         AccK<K> acc;
         acc.init();
         walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
-        if (!finite) acc.init_nan();
+        if (!in_dom) acc.init_nan();
         if (alive) {
 #pragma unroll
             for (int j = 0; j < K; ++j)
@@ -1469,7 +1469,7 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
     const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
     dx = dx / dl; dy = dy / dl; dz = dz / dl;
     float t = mp.t_min;
-    bool alive = inside && finite3(dx, dy, dz) && march_domain(ox, oy, oz, mp.t_min), hit = false;
+    bool alive = inside && in_domain3(dx, dy, dz) && march_domain(ox, oy, oz, mp.t_min), hit = false;
     const float t_hi = march_t_hi(mp.t_max);
     uint32_t hit_prim = SDF_NO_PRIM;
     float px = 0.f, py = 0.f, pz = 0.f;
