@@ -42,6 +42,14 @@ pub struct MarchParams {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
+pub struct Stats {   // sdfgpu_stats
+    pub queries: u64, pub inner_visits: u64, pub sphere_evals: u64, pub box_evals: u64,
+    pub wave_inner: u64, pub wave_leaf: u64, pub steps: u64, pub rays: u64,
+    pub wave_steps: u64, pub wave_walks: u64, pub inner_needed: u64, pub sphere_needed: u64, pub box_needed: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct TreeInfo {
     pub n_nodes: u32,
     pub n_prims: u32,
@@ -125,6 +133,24 @@ extern "C" {
     fn sdfgpu_render_dev(ctx: *mut Ctx, cam: *const Camera, width: u32, height: u32, mp: *const MarchParams,
                          d_hit: *mut u8, d_depth: *mut f32, d_normal_xyz: *mut f32, d_prim: *mut u32,
                          stream: *mut c_void) -> c_int;
+    pub fn sdfgpu_status_string(status: c_int) -> *const c_char;
+    pub fn sdfgpu_sync(ctx: *mut Ctx) -> c_int;
+    /// the host half of an upload alone (validation + compaction, no GPU touched)
+    pub fn sdfgpu_compact_host(dt: *const SdfOperationBlock, ut: *const SdfOperationUptreeBlock, buffer_len: u32,
+                               layout: u32, bounds: u32, info: *mut TreeInfo, errbuf: *mut c_char, errlen: usize) -> c_int;
+    pub fn sdfgpu_compact_host_ext(dt: *const SdfOperationBlock, ut: *const SdfOperationUptreeBlock, buffer_len: u32,
+                                   layout: u32, bounds: u32, extensions: u32, info: *mut TreeInfo,
+                                   errbuf: *mut c_char, errlen: usize) -> c_int;
+    /// tile-compact planes of one share -> row-major frame (the single-share form of sdfgpu_untile_gathered_dev)
+    pub fn sdfgpu_untile_dev(ctx: *mut Ctx, width: u32, height: u32, tile_first: u32, tile_stride: u32, tile_count: u32,
+                             d_hit_t: *const u8, d_depth_t: *const f32, d_normal_t: *const f32, d_prim_t: *const u32,
+                             d_hit: *mut u8, d_depth: *mut f32, d_normal_xyz: *mut f32, d_prim: *mut u32,
+                             stream: *mut c_void) -> c_int;
+    // work counters of the instrumented kernels (what bench.py's roofline units come from)
+    pub fn sdfgpu_render_stats(ctx: *mut Ctx, cam: *const Camera, width: u32, height: u32, mp: *const MarchParams,
+                               out: *mut Stats) -> c_int;
+    pub fn sdfgpu_nearest_stats_dev(ctx: *mut Ctx, d_pts_xyzw: *const f32, n: usize, out: *mut Stats) -> c_int;
+    pub fn sdfgpu_knn_stats_dev(ctx: *mut Ctx, d_pts_xyzw: *const f32, n: usize, k: u32, out: *mut Stats) -> c_int;
     fn sdfgpu_set_option(ctx: *mut Ctx, option: c_int, value: f64) -> c_int;
     fn sdfgpu_camera_look_at(eye: *const f32, target: *const f32, up: *const f32, fov_y: f32, width: u32,
                              height: u32, out: *mut Camera);
