@@ -40,6 +40,10 @@ def run(seed, iters, gpu=None, log=print, heavy=False):
       pts = np.ones((m, 4), np.float32)
       spread = float(rng.choice([1.0, 30.0, 1e3]))
       pts[:, :3] = (offset + scale * spread * rng.uniform(-1, 1, (m, 3))).astype(np.float32)
+      if heavy:   # points far outside the scene: the unclamped copy of the walk (kernels.hip, FAR)
+          u = rng.normal(size=(150, 3))
+          u /= np.linalg.norm(u, axis=1, keepdims=True)
+          pts[-150:, :3] = (offset + u * scale * 20 * rng.choice([20.0, 300.0, 3e4], size=(150, 1))).astype(np.float32)
       pts[: min(n, 50), :3] = [buf.downtree_buffer[i]["bounding_box"]["matrix"][12:15] for i in np.flatnonzero(buf.downtree_buffer["is_primitive"])[: min(n, 50)]]  # primitive centres
       d0, i0 = O.nearest(buf, pts, mode=O.MODE_EXHAUSTIVE, threads=8)
       k = int(rng.choice([1, 3, 8, 16]))
