@@ -17,3 +17,12 @@ def test_static_entry_point_replays_from_a_graph(gpu):
 
     msgs = []
     assert graph_probe.run(log=msgs.append), msgs
+
+
+def test_a_frame_replays_from_a_graph(gpu):
+    # sdfgpu_render_dev allocates its per-stream scratch on the first call on a stream; after that warm-up the
+    # whole frame (tile schedule, eye walk, march) can be captured and replayed (tools/graph_frame_probe.py)
+    import graph_frame_probe
+
+    msgs = []
+    assert graph_frame_probe.run(log=msgs.append, config=2, frames=5), msgs
