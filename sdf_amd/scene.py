@@ -184,23 +184,38 @@ class ExpandedSdfNode:
         b = lib.sdfhost_make_buffer(self._h, _opts(self._opts))
         if not b:
             raise SdfError(_host_err())
-        try:
-            n = lib.sdfhost_buffer_len(b)
-            if n == 0:
-                return SdfTreeBuffer.make_empty()
-            dt = np.ctypeslib.as_array(
-                C.cast(lib.sdfhost_buffer_downtree(b), C.POINTER(C.c_uint8)), shape=(n * 624,)
-            ).copy()
-            ut = np.ctypeslib.as_array(
-                C.cast(lib.sdfhost_buffer_uptree(b), C.POINTER(C.c_uint8)), shape=(n * 224,)
-            ).copy()
-            return SdfTreeBuffer(dt.view(_ffi.DT_DTYPE), ut.view(_ffi.UT_DTYPE))
-        finally:
+        n = lib.sdfhost_buffer_len(b)
+        if n == 0:
             lib.sdfhost_buffer_free(b)
+            return SdfTreeBuffer.make_empty()
+        # The arrays view the builder's own memory (170 MB for 100k primitives: copying it cost as much as
+        # building it); the C buffer lives as long as either array, or any view of one, does.
+        owner = _HostBuffer(lib, b)
+
+        def view(ptr, nbytes, dtype):
+            raw = (C.c_uint8 * nbytes).from_address(ptr)
+            raw._owner = owner   # numpy keeps `raw` as the array's base, `raw` keeps the C buffer
+            return np.frombuffer(raw, dtype=np.uint8).view(dtype)
+
+        dt = view(C.cast(lib.sdfhost_buffer_downtree(b), C.c_void_p).value, n * 624, _ffi.DT_DTYPE)
+        ut = view(C.cast(lib.sdfhost_buffer_uptree(b), C.c_void_p).value, n * 224, _ffi.UT_DTYPE)
+        return SdfTreeBuffer(dt, ut)
 
     def __del__(self):
         if getattr(self, "_h", None):
             _ffi.load_library().sdfhost_expanded_free(self._h)
+            self._h = None
+
+
+class _HostBuffer:
+    """Owner of one sdfhost_buffer (freed when the last array viewing it goes away)."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def __del__(self):
+        if self._h:
+            self._lib.sdfhost_buffer_free(self._h)
             self._h = None
 
 
