@@ -22,7 +22,38 @@ import os
 import sys
 import time
 
-import numpy as np
+
+
+def _self_launch_before_hip():
+    """`python bench.py --gpus N` (N > 1) without a launcher's environment: start the N ranks here, as fresh
+    child processes of `python -m torch.distributed.run`, BEFORE this process imports torch or touches HIP
+    (a process that has initialised the GPU must never be replaced or forked into ranks), pass rank 0's one
+    JSON line through, and exit with the children's status.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, arg in enumerate(sys.argv):
+        if arg == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif arg.startswith("--gpus="):
+            n = int(arg.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool's hosts
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+_self_launch_before_hip()
+import numpy as np  # noqa: E402
 
 
 def _hw_queues_before_hip():
@@ -81,7 +112,11 @@ def parse():
                     help="diagnostic (1 GPU): render only rank 0's tile share of an N-rank frame, no gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the N-rank path)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for every rank (rehearsal: N ranks on one GPU); default LOCAL_RANK")
-    ap.add_argument("--torch-gather", action="store_true", help="N > 1: assemble with torch.distributed all-gather instead of the library's communicator")
+    ap.add_argument("--lib-comm", action="store_true",
+                    help="N > 1: the timed frames go through the library's own communicator (sdfgpu_render_frame_comm: grouped "
+                         "ncclSend / ncclRecv to rank 0) instead of torch.distributed's RCCL all-gather.  Until a multi-GPU record of "
+                         "that path exists it is measured as a separate, watchdog-guarded leg after the headline (line['lib_comm'])")
+    ap.add_argument("--no-lib-comm-leg", action="store_true", help="N > 1: skip the library-communicator leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the variants leg (profiling: kernel averages then cover the timed frames only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-knn", action="store_true", help="skip the kNN (config 5) leg")
@@ -416,6 +451,97 @@ def variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev):
     return out
 
 
+def make_lib_comm(gpu, rank, world, dist, dev, cam, w, h, mp, slots):
+    """The library's communicator over the ranks of this job, or None (on every rank alike) when it cannot be
+    made or its trial frame reports an error."""
+    comm = None
+    try:
+        box = [S.SdfComm.make_id(gpu) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = S.SdfComm(gpu, box[0], rank, world)
+    except Exception as e:   # noqa: BLE001
+        print(f"[bench rank {rank}] library communicator unavailable ({e})", file=sys.stderr)
+        comm = None
+    ok = torch.tensor([1 if comm is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None
+    good = 1
+    try:   # one trial frame: an error it reports (as opposed to a hang) sends every rank back to the torch path
+        sl = slots[0]
+        comm.render_frame(cam, w, h, mp, 0, *(sl.out_ptrs if rank == 0 else (0, 0, 0, 0)), sl.stream.cuda_stream)
+        torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001
+        print(f"[bench rank {rank}] library communicator failed on its trial frame ({e})", file=sys.stderr)
+        good = 0
+    ok = torch.tensor([good], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        comm.close()
+        return None
+    return comm
+
+
+def lib_comm_leg(a, gpu, rank, world, dist, dev, cam, w, h, mp, slots, depth, line, knn):
+    """N > 1, last thing in the run: the same frames through sdfgpu_render_frame_comm.  The path is unexercised on
+    real multi-GPU hardware, and a collective that goes wrong hangs a stream rather than raising, so a watchdog
+    thread prints the line WITHOUT this leg's numbers and ends the process if the leg does not finish in time."""
+    import threading
+    done = threading.Event()
+    limit = float(os.environ.get("SDF_BENCH_LIBCOMM_TIMEOUT", "90"))
+
+    def watchdog():
+        if done.wait(limit):
+            return
+        if rank == 0:
+            line["lib_comm"] = {"status": f"did not finish within {limit:.0f} s (hang in the exchange?); headline unaffected"}
+            if knn is not None:
+                line["knn"] = knn
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    out = {"status": "communicator could not be made or failed its trial frame"}
+    comm = make_lib_comm(gpu, rank, world, dist, dev, cam, w, h, mp, slots)
+    if comm is not None:
+        npix = w * h
+        ref = None
+        if rank == 0:   # the frame the torch path assembled (slot 0 holds it), to compare with
+            sl = slots[0]
+            ref = [t.clone() for t in (sl.o_hit, sl.o_depth, sl.o_normal, sl.o_prim)]
+
+        def step(k):
+            sl = slots[k % depth]
+            comm.render_frame(cam, w, h, mp, 0, *(sl.out_ptrs if rank == 0 else (0, 0, 0, 0)), sl.stream.cuda_stream)
+
+        for k in range(2 * depth):
+            step(k)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            step(k)
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        out = {"status": "ok", "value": npix * a.steps / el / 1e6, "unit": "Mrays/s", "ms_per_step": el / a.steps * 1e3,
+               "gather": "RCCL grouped ncclSend / ncclRecv to rank 0 + untile (sdfgpu_render_frame_comm)"}
+        if rank == 0:
+            sl = slots[0]
+            same = (torch.equal(ref[0], sl.o_hit) and torch.equal(ref[3], sl.o_prim)
+                    and torch.equal(ref[1].view(torch.int32), sl.o_depth.view(torch.int32))
+                    and torch.equal(ref[2].view(torch.int32), sl.o_normal.view(torch.int32)))
+            out["assembly_check"] = "bit-identical to the torch all-gather frame" if same else "MISMATCH"
+        comm.close()
+    done.set()
+    return out
+
+
 def trace(msg):
     """Stage markers for rehearsing the N-rank path (SDF_BENCH_TRACE=1)."""
     if os.environ.get("SDF_BENCH_TRACE"):
@@ -429,9 +555,7 @@ def main():
     if a.device >= 0:
         local_rank = a.device
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != a.gpus:   # (--gpus N without a launcher never gets here: _self_launch_before_hip started the ranks)
         a.gpus = world
     dist = None
     if world > 1:
@@ -509,39 +633,11 @@ def main():
             sl.mine_ptrs = tuple(t.data_ptr() for t in P.planes(sl.mine, world, tiles))
             sl.out_ptrs = (sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(), sl.o_prim.data_ptr())
 
-        # Assembly through the library's own communicator (sdfgpu_render_frame_comm: tile share ->
-        # grouped ncclSend / ncclRecv to rank 0 -> untile), the path a host without torch uses.  If
-        # the communicator cannot be made, the torch.distributed all-gather path below does the same job.
-        comm = None
-        if a.backend == "nccl" and not a.torch_gather:
-            try:
-                box = [S.SdfComm.make_id(gpu) if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = S.SdfComm(gpu, box[0], rank, world)
-            except Exception as e:   # noqa: BLE001
-                print(f"[bench rank {rank}] library communicator unavailable ({e}); using torch all-gather", file=sys.stderr)
-                comm = None
-            ok = torch.tensor([1 if comm is not None else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and comm is not None:
-                comm.close()
-                comm = None
-            if comm is not None:
-                # one trial frame through the communicator: an error it reports (as opposed to a hang) sends
-                # every rank to the torch path instead of ending the run
-                good = 1
-                try:
-                    sl = slots[0]
-                    comm.render_frame(cam, w, h, mp, 0, *(sl.out_ptrs if rank == 0 else (0, 0, 0, 0)), sl.stream.cuda_stream)
-                    torch.cuda.synchronize()
-                except Exception as e:   # noqa: BLE001
-                    print(f"[bench rank {rank}] library communicator failed on its trial frame ({e}); using torch all-gather", file=sys.stderr)
-                    good = 0
-                ok = torch.tensor([good], device=dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    comm.close()
-                    comm = None
+        # Assembly.  Default: torch.distributed's RCCL all-gather of the packed shares + one untile launch on rank 0.
+        # --lib-comm: the library's own communicator (sdfgpu_render_frame_comm: tile share -> grouped ncclSend /
+        # ncclRecv to rank 0 -> untile), the path a host without torch uses.  That path has never run on more than
+        # one GPU, so by default it is a separate leg after the headline, guarded by a watchdog (lib_comm_leg).
+        comm = make_lib_comm(gpu, rank, world, dist, dev, cam, w, h, mp, slots) if (a.lib_comm and a.backend == "nccl") else None
         gather_kind = "RCCL grouped send/recv to rank 0 (sdfgpu_render_frame_comm)" if comm is not None else (f"{a.backend} all-gather (torch.distributed)")
 
         def step(k=0):
@@ -679,6 +775,10 @@ def main():
     knn = None
     if not a.no_knn:
         knn = knn_leg(a, rank, world, local_rank, dev, dist)
+    if world > 1 and a.backend == "nccl" and not a.lib_comm and not a.no_lib_comm_leg:
+        leg = lib_comm_leg(a, gpu, rank, world, dist, dev, cam, w, h, mp, slots, depth, line, knn)
+        if rank == 0:
+            line["lib_comm"] = leg
     if rank == 0:
         if knn is not None:
             line["knn"] = knn

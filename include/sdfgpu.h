@@ -343,6 +343,49 @@ int sdfgpu_render_frame_comm(sdfgpu_ctx* ctx, sdfgpu_comm* comm, const sdfgpu_ca
                              uint32_t width, uint32_t height, const sdfgpu_march_params* mp, int root,
                              uint8_t* d_hit, float* d_depth, float* d_normal_xyz, uint32_t* d_prim,
                              void* hip_stream);
+/* Rules of a frame across a communicator (it is a collective):
+ *  - every rank passes IDENTICAL width / height / march parameters / camera / root; nothing checks that across
+ *    ranks, and ranks that disagree about the frame's size disagree about the size of the exchange;
+ *  - everything that can fail locally is done before anything a peer waits on, and a rank whose own march
+ *    failed (no tree uploaded, ...) still takes part in the exchange -- its share arrives as misses -- and
+ *    returns its error afterwards; a rank that cannot take part at all (its staging could not be allocated)
+ *    aborts the communicator (ncclCommAbort): its peers' pending operations then end with an error instead of
+ *    hanging, and every later call on that communicator returns SDFGPU_ERR_COMM;
+ *  - the first frame of a (communicator, stream, size) allocates staging and must run outside stream capture;
+ *  - destroy communicators BEFORE the context they were created on (sdfgpu_destroy does not know them);
+ *  - frames of one communicator on several streams may be in flight together, but RCCL orders the operations
+ *    of one communicator, so their exchanges run one after the other;
+ *  - UNEXERCISED ON MORE THAN ONE GPU: no multi-GPU machine was in reach of this build.  What has run: the
+ *    world-1 path, and the grouped ncclSend / ncclRecv / untile-from-gathered path through a send to self
+ *    (SDFGPU_COMM_SELF_EXCHANGE=1 in the environment of the create call makes the assembling rank exchange its
+ *    own share with itself; tests/test_gpu_comm.py). */
+
+/* One process, several GPUs (SURVEY 8b/8e "ncclCommInitAll"): a clique over n contexts, each on its own
+ * device, rank i = ctxs[i]; no id exchange.  comms_out receives n communicators (destroy each with
+ * sdfgpu_comm_destroy).  sdfgpu_render_frame_all is sdfgpu_render_frame_comm for all n ranks from the one
+ * calling thread: every rank's tile share on its own device and stream (hip_streams[i], NULL array = the null
+ * stream everywhere), then ONE ncclGroupStart / GroupEnd around all sends and receives, then the assembly on
+ * `root`, whose device the output pointers belong to.  No counterpart in the reference.  Unexercised on more
+ * than one GPU (see above); world 1 is covered by tests/test_gpu_comm.py. */
+int sdfgpu_comm_create_all(sdfgpu_ctx* const* ctxs, int n, sdfgpu_comm** comms_out);
+int sdfgpu_render_frame_all(sdfgpu_comm* const* comms, int n, const sdfgpu_camera* cam,
+                            uint32_t width, uint32_t height, const sdfgpu_march_params* mp, int root,
+                            uint8_t* d_hit, float* d_depth, float* d_normal_xyz, uint32_t* d_prim,
+                            void* const* hip_streams);
+
+/* ---- query-batch partitioner --------------------------------------------- */
+/* No reference counterpart.  A batch of n queries is cut into `world` contiguous slices (the first n % world
+ * slices one longer): sdfgpu_query_slice gives slice `rank` as [*first, *first + *count).  The sharded entry
+ * points run one batch of HOST points over n_ctx contexts (each with the same tree uploaded; one per GPU, or
+ * several on one GPU): slice i is copied to ctxs[i]'s device, queried there (sdfgpu_nearest_dev /
+ * sdfgpu_knn_dev), and copied back into the caller's arrays at the slice's place, all contexts in flight
+ * together; the call returns when every slice is back.  Results are exactly those of the unsharded call.
+ * (A host whose points already live on the devices calls the _dev entry points per context itself.) */
+void sdfgpu_query_slice(size_t n, uint32_t rank, uint32_t world, size_t* first, size_t* count);
+int sdfgpu_nearest_sharded(sdfgpu_ctx* const* ctxs, int n_ctx, const float* pts_xyzw, size_t n,
+                           float* out_dist, uint32_t* out_prim);
+int sdfgpu_knn_sharded(sdfgpu_ctx* const* ctxs, int n_ctx, const float* pts_xyzw, size_t n, uint32_t k,
+                       float* out_dist, uint32_t* out_prim);
 
 /* ---- instrumentation ---------------------------------------------------- */
 /* Run the counting variant of the same kernels (slower) and return the work

@@ -115,6 +115,18 @@ extern "C" {
     pub fn sdfgpu_render_frame_comm(ctx: *mut Ctx, comm: *mut Comm, cam: *const Camera, width: u32, height: u32,
                                     mp: *const MarchParams, root: c_int, d_hit: *mut u8, d_depth: *mut f32,
                                     d_normal_xyz: *mut f32, d_prim: *mut u32, stream: *mut c_void) -> c_int;
+    // one process driving several GPUs: a clique over n contexts (ncclCommInitAll), every rank's frame share from
+    // the one calling thread inside ONE ncclGroupStart / GroupEnd
+    pub fn sdfgpu_comm_create_all(ctxs: *const *mut Ctx, n: c_int, comms_out: *mut *mut Comm) -> c_int;
+    pub fn sdfgpu_render_frame_all(comms: *const *mut Comm, n: c_int, cam: *const Camera, width: u32, height: u32,
+                                   mp: *const MarchParams, root: c_int, d_hit: *mut u8, d_depth: *mut f32,
+                                   d_normal_xyz: *mut f32, d_prim: *mut u32, streams: *const *mut c_void) -> c_int;
+    // query-batch partitioner: contiguous slices of a host batch over several contexts, results assembled in place
+    pub fn sdfgpu_query_slice(n: usize, rank: u32, world: u32, first: *mut usize, count: *mut usize);
+    pub fn sdfgpu_nearest_sharded(ctxs: *const *mut Ctx, n_ctx: c_int, pts_xyzw: *const f32, n: usize,
+                                  out_dist: *mut f32, out_prim: *mut u32) -> c_int;
+    pub fn sdfgpu_knn_sharded(ctxs: *const *mut Ctx, n_ctx: c_int, pts_xyzw: *const f32, n: usize, k: u32,
+                              out_dist: *mut f32, out_prim: *mut u32) -> c_int;
     // the pieces of the same assembly for a host that brings its own collective: a rank's tile share into a
     // packed buffer of sdfgpu_packed_share_bytes, every rank's buffer into the frame in one launch
     pub fn sdfgpu_render_tiles_dev(ctx: *mut Ctx, cam: *const Camera, width: u32, height: u32, mp: *const MarchParams,

@@ -9,7 +9,8 @@ from . import _ffi
 from ._ffi import (BOUNDS_AABB, BOUNDS_AUTO, BOUNDS_BVH, BOUNDS_NONE, BOUNDS_OBB, EXT_BOX_FRAME,
                    EXT_CLONE_REPAIR, EXT_SMOOTH_UNION, NO_PRIM,
                    Camera, MarchParams, load_library)
-from .gpu import SdfComm, SdfGpu, SdfGpuError, camera_look_at, compact_host, march_params
+from .gpu import (SdfComm, SdfGpu, SdfGpuError, camera_look_at, compact_host, knn_sharded, march_params, nearest_sharded,
+                  query_slice)
 from .scene import (ExpandedSdfNode, Quat, SdfBox, SdfBoxFrame, SdfBuilder, SdfCaaClone, SdfError, SdfNode,
                     SdfSphere, SdfTreeBuffer, SdfUnion, Transform, default_extent,
                     random_scene, random_scene_buffer)

@@ -164,6 +164,12 @@ GPU_SYMBOLS = {
     "sdfgpu_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "sdfgpu_comm_destroy": (None, [_vp]),
     "sdfgpu_render_frame_comm": (_i, [_vp, _vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _i, _vp, _vp, _vp, _vp, _vp]),
+    "sdfgpu_comm_create_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "sdfgpu_render_frame_all": (_i, [C.POINTER(_vp), _i, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), _i, _vp, _vp, _vp, _vp,
+                                     C.POINTER(_vp)]),
+    "sdfgpu_query_slice": (None, [_sz, _u32, _u32, C.POINTER(_sz), C.POINTER(_sz)]),
+    "sdfgpu_nearest_sharded": (_i, [C.POINTER(_vp), _i, _vp, _sz, _vp, _vp]),
+    "sdfgpu_knn_sharded": (_i, [C.POINTER(_vp), _i, _vp, _sz, _u32, _vp, _vp]),
     "sdfgpu_render_stats": (_i, [_vp, C.POINTER(Camera), _u32, _u32, C.POINTER(MarchParams), C.POINTER(Stats)]),
     "sdfgpu_nearest_stats_dev": (_i, [_vp, _vp, _sz, C.POINTER(Stats)]),
     "sdfgpu_knn_stats_dev": (_i, [_vp, _vp, _sz, _u32, C.POINTER(Stats)]),

@@ -662,6 +662,79 @@ int sdfgpu_knn(sdfgpu_ctx* c, const float* pts, size_t n, uint32_t k, float* out
     return SDFGPU_OK;
 }
 
+void sdfgpu_query_slice(size_t n, uint32_t rank, uint32_t world, size_t* first, size_t* count) {
+    size_t lo = 0, cnt = 0;
+    if (world != 0 && rank < world) {
+        const size_t base = n / world, rem = n % world;
+        lo = (size_t)rank * base + (rank < rem ? rank : rem);
+        cnt = base + (rank < rem ? 1u : 0u);
+    }
+    if (first) *first = lo;
+    if (count) *count = cnt;
+}
+
+// One host batch over several contexts (k == 0: the k = 1 query without rows).  Every context's slice is
+// queued on that context's own stream before any is waited for, so the devices work side by side.
+static int query_sharded(sdfgpu_ctx* const* ctxs, int n_ctx, const float* pts, size_t n, uint32_t k, float* out_dist,
+                         uint32_t* out_prim) {
+    if (!ctxs || n_ctx < 1) return SDFGPU_ERR_INVALID_ARG;
+    for (int i = 0; i < n_ctx; ++i)
+        if (!ctxs[i]) return SDFGPU_ERR_INVALID_ARG;
+    sdfgpu_ctx* c0 = ctxs[0];
+    const bool knn = k != 0;
+    const uint32_t kk = knn ? k : 1u;
+    if (knn && k > SDFGPU_MAX_K) return set_err(c0, SDFGPU_ERR_TOO_LARGE, "k must be in 1..SDFGPU_MAX_K (16)");
+    for (int i = 0; i < n_ctx; ++i) {
+        int rc = check_ready(ctxs[i]);
+        if (rc) return rc;
+    }
+    if (n == 0) return SDFGPU_OK;
+    if (!pts || !out_dist || (knn && !out_prim)) return set_err(c0, SDFGPU_ERR_INVALID_ARG, "null pointer");
+    for (size_t i = 0; i < n; ++i)
+        if (pts[4 * i + 3] != 1.0f) return set_err(c0, SDFGPU_ERR_POINT_W, "a query point has w != 1");
+    int first_rc = SDFGPU_OK;
+    for (int i = 0; i < n_ctx; ++i) {
+        sdfgpu_ctx* c = ctxs[i];
+        size_t lo, m;
+        sdfgpu_query_slice(n, (uint32_t)i, (uint32_t)n_ctx, &lo, &m);
+        if (m == 0) continue;
+        int rc = [&]() -> int {
+            HIP_TRY(c, hipSetDevice(c->device));
+            int r;
+            if ((r = reserve(c, c->in, m * 16)) || (r = reserve(c, c->out_a, m * kk * 4)) || (r = reserve(c, c->out_b, m * kk * 4))) return r;
+            HIP_TRY(c, hipMemcpyAsync(c->in.p, pts + 4 * lo, m * 16, hipMemcpyHostToDevice, c->stream));
+            r = knn ? sdfgpu_knn_dev(c, (const float*)c->in.p, m, k, (float*)c->out_a.p, (uint32_t*)c->out_b.p, c->stream)
+                    : sdfgpu_nearest_dev(c, (const float*)c->in.p, m, (float*)c->out_a.p, (uint32_t*)c->out_b.p, c->stream);
+            if (r) return r;
+            HIP_TRY(c, hipMemcpyAsync(out_dist + lo * kk, c->out_a.p, m * kk * 4, hipMemcpyDeviceToHost, c->stream));
+            if (out_prim) HIP_TRY(c, hipMemcpyAsync(out_prim + lo * kk, c->out_b.p, m * kk * 4, hipMemcpyDeviceToHost, c->stream));
+            return SDFGPU_OK;
+        }();
+        if (rc && !first_rc) {
+            first_rc = rc;
+            if (c != c0) c0->err = c->err;   // the caller reads the message from the first context
+            break;
+        }
+    }
+    for (int i = 0; i < n_ctx; ++i) {   // wait for whatever was queued, also after a failure
+        sdfgpu_ctx* c = ctxs[i];
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            if (!first_rc) first_rc = set_err(c0, SDFGPU_ERR_HIP, "hipStreamSynchronize (sharded query)");
+        }
+    }
+    return first_rc;
+}
+
+int sdfgpu_nearest_sharded(sdfgpu_ctx* const* ctxs, int n_ctx, const float* pts, size_t n, float* out_dist, uint32_t* out_prim) {
+    return query_sharded(ctxs, n_ctx, pts, n, 0u, out_dist, out_prim);
+}
+
+int sdfgpu_knn_sharded(sdfgpu_ctx* const* ctxs, int n_ctx, const float* pts, size_t n, uint32_t k, float* out_dist,
+                       uint32_t* out_prim) {
+    if (k == 0) return ctxs && n_ctx > 0 && ctxs[0] ? set_err(ctxs[0], SDFGPU_ERR_TOO_LARGE, "k must be in 1..SDFGPU_MAX_K (16)") : SDFGPU_ERR_INVALID_ARG;
+    return query_sharded(ctxs, n_ctx, pts, n, k, out_dist, out_prim);
+}
+
 int sdfgpu_box_bounds(sdfgpu_ctx* c, const SdfBoundingBoxBlock* box, const float* pts, size_t n, float* out_min,
                       float* out_max) {
     if (!c) return SDFGPU_ERR_INVALID_ARG;

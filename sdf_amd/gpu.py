@@ -53,9 +53,12 @@ class SdfGpu:
             raise SdfGpuError(rc, f"sdfgpu_create(device={device}) failed: " + self._lib.sdfgpu_status_string(rc).decode())
         self._h = h
         self.device = device
+        self._comms = []   # live communicators made on this context: closed before it (sdfgpu.h: destroy them first)
 
     def close(self):
         if getattr(self, "_h", None):
+            for m in list(getattr(self, "_comms", [])):
+                m.close()
             self._lib.sdfgpu_destroy(self._h)
             self._h = None
 
@@ -217,15 +220,74 @@ class SdfComm:
         gpu._check(gpu._lib.sdfgpu_comm_create(gpu._h, id_bytes, rank, world, C.byref(h)))
         self._h = h
         self.rank, self.world = rank, world
+        gpu._comms.append(self)
 
     def render_frame(self, cam, width, height, mp, root, d_hit, d_depth, d_normal, d_prim, stream=0):
         g = self._gpu
         g._check(g._lib.sdfgpu_render_frame_comm(g._h, self._h, C.byref(cam), width, height, C.byref(mp), root,
                                                  d_hit, d_depth, d_normal, d_prim, stream))
 
+    @classmethod
+    def create_all(cls, gpus):
+        """One process, several GPUs: a clique over the contexts (sdfgpu_comm_create_all, ncclCommInitAll);
+        returns one SdfComm per context, rank i = gpus[i]."""
+        n = len(gpus)
+        ctxs = (C.c_void_p * n)(*[g._h for g in gpus])
+        out = (C.c_void_p * n)()
+        gpus[0]._check(gpus[0]._lib.sdfgpu_comm_create_all(ctxs, n, out))
+        comms = []
+        for i, g in enumerate(gpus):
+            m = cls.__new__(cls)
+            m._gpu, m._h, m.rank, m.world = g, C.c_void_p(out[i]), i, n
+            g._comms.append(m)
+            comms.append(m)
+        return comms
+
+    @staticmethod
+    def render_frame_all(comms, cam, width, height, mp, root, d_hit, d_depth, d_normal, d_prim, streams=None):
+        """sdfgpu_render_frame_all: every rank of an in-process clique from this one thread."""
+        n = len(comms)
+        hs = (C.c_void_p * n)(*[m._h for m in comms])
+        st = (C.c_void_p * n)(*streams) if streams is not None else None
+        g = comms[root]._gpu
+        g._check(g._lib.sdfgpu_render_frame_all(hs, n, C.byref(cam), width, height, C.byref(mp), root,
+                                                d_hit, d_depth, d_normal, d_prim, st))
+
     def close(self):
         if getattr(self, "_h", None):
             self._gpu._lib.sdfgpu_comm_destroy(self._h)
             self._h = None
+        if getattr(self, "_gpu", None) is not None and self in self._gpu._comms:
+            self._gpu._comms.remove(self)
 
     __del__ = close
+
+
+def query_slice(n, rank, world):
+    """(first, count) of slice `rank` of a batch of n queries cut into `world` contiguous slices (sdfgpu_query_slice)."""
+    lo, cnt = C.c_size_t(), C.c_size_t()
+    _ffi.load_library().sdfgpu_query_slice(n, rank, world, C.byref(lo), C.byref(cnt))
+    return lo.value, cnt.value
+
+
+def _sharded(gpus, pts_xyzw, k):
+    p = np.ascontiguousarray(pts_xyzw, dtype=np.float32).reshape(-1, 4)
+    n = p.shape[0]
+    ctxs = (C.c_void_p * len(gpus))(*[g._h for g in gpus])
+    dist = np.empty((n, k) if k else n, np.float32)
+    prim = np.empty((n, k) if k else n, np.uint32)
+    lib = gpus[0]._lib
+    if k:
+        gpus[0]._check(lib.sdfgpu_knn_sharded(ctxs, len(gpus), p.ctypes.data, n, k, dist.ctypes.data, prim.ctypes.data))
+    else:
+        gpus[0]._check(lib.sdfgpu_nearest_sharded(ctxs, len(gpus), p.ctypes.data, n, dist.ctypes.data, prim.ctypes.data))
+    return dist, prim
+
+
+def nearest_sharded(gpus, pts_xyzw):
+    """One host batch cut into contiguous slices over several contexts (sdfgpu_nearest_sharded)."""
+    return _sharded(gpus, pts_xyzw, 0)
+
+
+def knn_sharded(gpus, pts_xyzw, k):
+    return _sharded(gpus, pts_xyzw, k)
