@@ -79,7 +79,7 @@ typedef struct sdfgpu_tree_info {
     float scene_lo[3];       /* root AABB (AABB mode) */
     float scene_hi[3];
     uint32_t extensions;     /* sdfgpu_extension bits that are in effect in this tree (0 = evaluated as the crate is written) */
-    uint32_t reserved;
+    uint32_t grid_cells;     /* cells of the nearest-candidate grid built for the march (0 = none); its bytes are part of device_bytes */
 } sdfgpu_tree_info;
 
 /* Pinhole camera as plain data.  Ray through pixel (x, y):
@@ -126,6 +126,9 @@ typedef struct sdfgpu_stats {
     uint64_t inner_needed;   /* internal-node visits a lane itself needed (<= inner_visits: the wave visits the union) */
     uint64_t sphere_needed;  /* primitive evaluations a lane itself needed: seeds, and leaves its own bound asked for */
     uint64_t box_needed;
+    uint64_t list_steps;     /* march steps (summed over rays) decided on a grid cell's candidate list instead of a walk */
+    uint64_t wave_lists;     /* list passes, counted once per wavefront */
+    uint64_t wave_list_evals;/* primitive evaluations of those passes, counted once per wavefront */
 } sdfgpu_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -248,7 +251,14 @@ typedef enum sdfgpu_option {
      * beside the walk of chunk i.  Ordering with the caller's stream is kept with events; the call stays
      * asynchronous.  Off by default: on MI355X every extra chunk cost ~0.3 ms on the 10 M point batch
      * (2.15 ms in one piece, 2.46 / 3.02 / 4.22 ms in 2 / 4 / 8 chunks). */
-    SDFGPU_OPT_QUERY_PIPELINE = 5
+    SDFGPU_OPT_QUERY_PIPELINE = 5,
+    /* render: 1 (default): sdfgpu_upload_tree also builds the nearest-candidate grid (a uniform grid over the
+     * padded scene box whose cells list every primitive that can be nearest anywhere in the cell; about 10 bytes
+     * per cell, ~400 cells per primitive, at most 32 M cells), and march steps inside it are decided on a cell's
+     * list instead of a tree walk.  0: no grid (set BEFORE the upload; a tree already resident keeps what it
+     * has).  Built for pruned trees (AABB / BVH bounds) of at least 64 primitives.  Results are identical
+     * either way. */
+    SDFGPU_OPT_CANDIDATE_GRID = 6
 } sdfgpu_option;
 int sdfgpu_set_option(sdfgpu_ctx* ctx, int option, double value);
 

@@ -46,6 +46,7 @@ pub struct Stats {   // sdfgpu_stats
     pub queries: u64, pub inner_visits: u64, pub sphere_evals: u64, pub box_evals: u64,
     pub wave_inner: u64, pub wave_leaf: u64, pub steps: u64, pub rays: u64,
     pub wave_steps: u64, pub wave_walks: u64, pub inner_needed: u64, pub sphere_needed: u64, pub box_needed: u64,
+    pub list_steps: u64, pub wave_lists: u64, pub wave_list_evals: u64,
 }
 
 #[repr(C)]
@@ -64,7 +65,8 @@ pub struct TreeInfo {
     pub scene_hi: [f32; 3],
     /// `sdfgpu_extension` bits in effect in this tree (0 = evaluated as the crate is written)
     pub extensions: u32,
-    pub reserved: u32,
+    /// cells of the nearest-candidate grid built for the march (0 = none)
+    pub grid_cells: u32,
 }
 
 pub const LAYOUT_GLAM_SSE2: u32 = 0;
@@ -77,6 +79,7 @@ pub const OPT_COMPACTION: i32 = 2;
 pub const OPT_TILE_ORDER: i32 = 3;
 pub const OPT_STATS_ASM_WALK: i32 = 4;
 pub const OPT_QUERY_PIPELINE: i32 = 5;
+pub const OPT_CANDIDATE_GRID: i32 = 6;
 /// `sdfgpu_extension`: opt-in evaluation of data the crate carries but never evaluates
 /// (elements.rs:207-211 smooth_radius, elements.rs:120-152 SdfBoxFrame, faux_shader.rs:90 clone).
 pub const EXT_SMOOTH_UNION: u32 = 1;

@@ -58,7 +58,7 @@ ERR_UNSUPPORTED_OP, ERR_TOO_DEEP, ERR_NON_FINITE, ERR_POINT_W, ERR_TOO_LARGE, ER
 COMM_ID_BYTES = 128
 MAX_K = 16
 STATIC_MAX_POINTS = 262144
-OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER, OPT_STATS_ASM_WALK, OPT_QUERY_PIPELINE = 0, 1, 2, 3, 4, 5
+OPT_REORDER, OPT_SKIP_EXTENSION, OPT_COMPACTION, OPT_TILE_ORDER, OPT_STATS_ASM_WALK, OPT_QUERY_PIPELINE, OPT_CANDIDATE_GRID = 0, 1, 2, 3, 4, 5, 6
 
 
 class TreeInfo(C.Structure):
@@ -75,7 +75,7 @@ class TreeInfo(C.Structure):
         ("scene_lo", C.c_float * 3),
         ("scene_hi", C.c_float * 3),
         ("extensions", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("grid_cells", C.c_uint32),
     ]
 
 
@@ -114,6 +114,9 @@ class Stats(C.Structure):
         ("inner_needed", C.c_uint64),
         ("sphere_needed", C.c_uint64),
         ("box_needed", C.c_uint64),
+        ("list_steps", C.c_uint64),
+        ("wave_lists", C.c_uint64),
+        ("wave_list_evals", C.c_uint64),
     ]
 
     def as_dict(self):

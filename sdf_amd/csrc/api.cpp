@@ -54,6 +54,7 @@ struct sdfgpu_ctx {
     std::vector<uint32_t> pass_steps;   // interior pass boundaries (march steps)
     bool reorder = true;
     bool stats_asm_walk = false;    // SDFGPU_OPT_STATS_ASM_WALK
+    bool candidate_grid = true;     // SDFGPU_OPT_CANDIDATE_GRID: the next upload builds the march's candidate grid
     // Large query batches: the batch is cut into chunks, and the Morton sort of chunk i + 1 (bandwidth-bound,
     // on the helper stream) runs beside the walk of chunk i (VALU-bound, on the caller's stream).
     uint32_t query_chunks = 0;      // SDFGPU_OPT_QUERY_PIPELINE (0 / 1: off, the default: measured slower)
@@ -103,6 +104,7 @@ void free_tree(sdfgpu_ctx* c) {
     if (c->tree.inner) (void)hipFree(c->tree.inner);
     if (c->tree.inner_obb) (void)hipFree(c->tree.inner_obb);
     if (c->tree.gen) (void)hipFree(c->tree.gen);
+    if (c->tree.grid.block) (void)hipFree(c->tree.grid.block);   // block, cells and brick ids are one allocation
     c->tree = DeviceTree();
     c->has_tree = false;
 }
@@ -354,6 +356,105 @@ int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint3
     return SDFGPU_OK;
 }
 
+// Environment overrides of the candidate grid's sizing (measurements; read once).
+double grid_env(const char* name, double dflt) {
+    const char* e = std::getenv(name);
+    return e && *e ? std::atof(e) : dflt;
+}
+
+// The nearest-candidate grid of the tree just uploaded (kernels.hpp CandidateGrid, grid.hip).  Geometry: the scene
+// box padded by an eighth of its largest extent on every side (rays enter and leave the scene through that margin,
+// and walks out there are the widest ones), cut into cells of equal size, ~400 per primitive (at the bench scenes'
+// density a cell is then about a fifth of the primitives' spacing: 2-3 candidates per cell), cells per axis a
+// multiple of 4 (bricks).  A failure to allocate is not an error: the tree simply has no grid.
+int build_grid(sdfgpu_ctx* c, const CompactTree& t) {
+    static const bool env_on = grid_env("SDFGPU_GRID", 1.0) != 0.0;
+    static const double per_prim = grid_env("SDFGPU_GRID_CELLS_PER_PRIM", 400.0);
+    static const double max_cells = grid_env("SDFGPU_GRID_MAX_CELLS", 32.0 * 1024 * 1024);
+    static const double pad_frac = grid_env("SDFGPU_GRID_PAD", 0.125);
+    constexpr uint32_t GRID_MIN_PRIMS = 64;
+    c->info.grid_cells = 0;
+    if (!env_on || !c->candidate_grid) return SDFGPU_OK;
+    const uint32_t b = t.info.bounds;
+    if (!t.gen.empty() || (b != SDFGPU_BOUNDS_AABB && b != SDFGPU_BOUNDS_BVH) || t.leaves.size() < GRID_MIN_PRIMS) return SDFGPU_OK;
+    if (!(t.lipschitz < 1.001f)) return SDFGPU_OK;   // rigid leaves only (what the pruned modes accept anyway)
+    float ext[3], maxext = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = t.info.scene_hi[a] - t.info.scene_lo[a];
+        if (!(ext[a] >= 0.f) || !(ext[a] < 1e30f)) return SDFGPU_OK;
+        maxext = std::fmax(maxext, ext[a]);
+    }
+    if (!(maxext > 0.f)) return SDFGPU_OK;
+    const float pad = (float)pad_frac * maxext;
+    double vol = 1.0;
+    float lo[3], len[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = t.info.scene_lo[a] - pad;
+        len[a] = ext[a] + 2.0f * pad;
+        vol *= (double)len[a];
+    }
+    const double target = std::fmin(max_cells, per_prim * (double)t.leaves.size());
+    const double side = std::cbrt(vol / target);
+    CandidateGrid g;
+    uint64_t cells = 1;
+    float diag2 = 0.f, p1max = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        double n = std::ceil((double)len[a] / side / 4.0) * 4.0;
+        n = std::fmin(std::fmax(n, 4.0), 2048.0);
+        g.n[a] = (uint32_t)n;
+        const float cell = len[a] / (float)g.n[a];
+        g.lo[a] = lo[a];
+        g.inv_cell[a] = 1.0f / cell;
+        if (!(g.inv_cell[a] > 0.f) || !(g.inv_cell[a] < 1e30f)) return SDFGPU_OK;
+        diag2 += cell * cell;
+        cells *= g.n[a];
+        p1max += std::fmax(std::fabs(lo[a]), std::fabs(lo[a] + len[a]));
+    }
+    if (cells > (uint64_t)(2.0 * max_cells) || cells >= (1ull << 31)) return SDFGPU_OK;
+    const uint64_t bricks = cells / 64u;
+    const float radius = 0.5f * std::sqrt(diag2) * 1.01f;   // + 1 %: a point's cell index is formed in fp32
+    // rounding of a leaf value anywhere in the grid (the prune margin of kernels.hip, at the largest |p|_1), times 8
+    const float e_max = 3.0e-6f * t.lipschitz * (p1max + t.margin_T);
+    const float margin = 8.0f * e_max;
+    const size_t cells_bytes = (cells * sizeof(GridCell) + 63u) & ~(size_t)63u;
+    const size_t ids_bytes = bricks * GRID_BRICK_IDS * sizeof(uint32_t);
+    g.bytes = sizeof(GridBlock) + cells_bytes + ids_bytes;
+    if (g.bytes >= (1ull << 32)) return SDFGPU_OK;   // the march addresses the tables with 32-bit offsets
+    if (hipMalloc(&g.block, g.bytes) != hipSuccess) { (void)hipGetLastError(); return SDFGPU_OK; }
+    g.cells = (GridCell*)((char*)g.block + sizeof(GridBlock));
+    g.brick_ids = (uint32_t*)((char*)g.block + sizeof(GridBlock) + cells_bytes);
+    const uint32_t chunk = (uint32_t)std::min<uint64_t>(bricks, 16384);   // 1 M cells per round: 144 MB of centres and rows
+    void* temp = nullptr;
+    if (hipMalloc(&temp, grid_temp_bytes(chunk)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(g.block);
+        return SDFGPU_OK;
+    }
+    GridBlock gb{};
+    for (int a = 0; a < 3; ++a) { gb.lo[a] = g.lo[a]; gb.inv_cell[a] = g.inv_cell[a]; gb.n[a] = g.n[a]; }
+    gb.nbx = g.n[0] / 4u;
+    gb.nby = g.n[1] / 4u;
+    gb.bricks_off = (uint32_t)(sizeof(GridBlock) + cells_bytes);
+    if (hipMemcpy(g.block, &gb, sizeof gb, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(temp);
+        (void)hipFree(g.block);
+        return SDFGPU_OK;
+    }
+    c->tree.grid = g;
+    hipError_t e = build_candidate_grid(c->tree, radius, margin, temp, chunk, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(temp);
+    if (e != hipSuccess) {
+        (void)hipFree(g.block);
+        c->tree.grid = CandidateGrid();
+        return hip_fail(c, e, "candidate grid build");
+    }
+    c->info.grid_cells = (uint32_t)cells;
+    c->info.device_bytes += g.bytes;
+    return SDFGPU_OK;
+}
+
 template <class T>
 int upload_vec(sdfgpu_ctx* c, const std::vector<T>& v, T** dst) {
     *dst = nullptr;
@@ -492,7 +593,7 @@ int sdfgpu_upload_tree_ext(sdfgpu_ctx* c, const SdfOperationBlock* dt, const Sdf
     c->info = t.info;
     c->has_tree = true;
     c->err.clear();
-    return SDFGPU_OK;
+    return build_grid(c, t);
 }
 
 int sdfgpu_upload_tree(sdfgpu_ctx* c, const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
@@ -620,6 +721,9 @@ int sdfgpu_set_option(sdfgpu_ctx* c, int option, double value) {
             return SDFGPU_OK;
         case SDFGPU_OPT_STATS_ASM_WALK:
             c->stats_asm_walk = value != 0.0;
+            return SDFGPU_OK;
+        case SDFGPU_OPT_CANDIDATE_GRID:
+            c->candidate_grid = value != 0.0;
             return SDFGPU_OK;
         case SDFGPU_OPT_TILE_ORDER:
             c->tile_order = value != 0.0;

@@ -180,6 +180,11 @@ struct TreeView {
     float lip;          // max change of any leaf value per unit the point moves, rounded up (1.000004 for rigid leaves)
     uint32_t prefetch;  // 1: the walk warms the scalar cache with both children's records (trees beyond one XCD's L2)
     uint32_t xcd;       // query kernels: each XCD works through a contiguous range of the batch (xcd_block; SDFGPU_XCD_ORDER=0 turns it off)
+    // nearest-candidate grid (kernels.hpp CandidateGrid) -- the march only.  One 64-byte block in HBM (GridBlock:
+    // geometry + the two table addresses), fetched by ONE scalar load at the start of a list pass: kept as kernel
+    // arguments its 13 values stayed live in SGPRs across the whole march loop and cost the kernel its eighth
+    // wavefront per SIMD (106 SGPRs).  Null: no grid.
+    const void* __restrict__ gblock;
 };
 
 // Absolute slack covering the rounding of a leaf value at point p (DESIGN.md "pruning").
@@ -191,7 +196,7 @@ __device__ __forceinline__ float prune_margin(const TreeView& T, float px, float
 }
 
 struct WaveCounters {
-    uint32_t wave_inner = 0, wave_leaf = 0, wave_steps = 0, wave_walks = 0;
+    uint32_t wave_inner = 0, wave_leaf = 0, wave_steps = 0, wave_walks = 0, wave_lists = 0, wave_list_evals = 0, lane_list_steps = 0;
     uint32_t lane_inner = 0, lane_sphere = 0, lane_box = 0, lane_queries = 0, lane_needed = 0;
     uint32_t lane_sphere_needed = 0, lane_box_needed = 0;   // ... of which the lane's own bound asked for
 };
@@ -266,6 +271,23 @@ __device__ __forceinline__ void load_rec128(const void* __restrict__ base, uint3
                  : "=&s"(a), "=&s"(b)
                  : "s"(base), "s"(off), "s"(off1)
                  : "memory");
+}
+
+// The same load into the SGPR tuple the assembly walk uses for its records (s[48:63]): the list pass of the march
+// and the walk never run at the same time, so sharing the tuple keeps the march kernel's SGPR count where it was.
+__device__ __forceinline__ f32x16 load_rec64_s48(const void* __restrict__ base, uint32_t idx) {
+    f32x16 r;
+    const uint32_t off = __builtin_amdgcn_readfirstlane(idx << 6);
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&{s[48:63]}"(r) : "s"(base), "s"(off) : "memory");
+    return r;
+}
+
+// One dword through the scalar cache (a wave-uniform table entry).
+__device__ __forceinline__ uint32_t load_u32_scalar(const void* __restrict__ base, uint32_t idx) {
+    uint32_t r;
+    const uint32_t off = __builtin_amdgcn_readfirstlane(idx << 2);
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(off) : "memory");
+    return r;
 }
 
 // Bits of one float element of such a record as an integer.  A plain bit cast of
@@ -651,10 +673,10 @@ __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float p
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
                                                sdfgpu_stats* st) {
     // wave-reduce the per-lane counters, one atomic per counter per wave
-    uint32_t v[9] = {wc.lane_queries, wc.lane_inner, wc.lane_sphere, wc.lane_box, steps, rays, wc.lane_needed,
-                     wc.lane_sphere_needed, wc.lane_box_needed};
+    uint32_t v[10] = {wc.lane_queries, wc.lane_inner, wc.lane_sphere, wc.lane_box, steps, rays, wc.lane_needed,
+                      wc.lane_sphere_needed, wc.lane_box_needed, wc.lane_list_steps};
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < 10; ++i)
         for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
     if (lane == 0) {
         atomicAdd((unsigned long long*)&st->queries, (unsigned long long)v[0]);
@@ -670,6 +692,9 @@ __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t 
         atomicAdd((unsigned long long*)&st->wave_leaf, (unsigned long long)wc.wave_leaf);
         atomicAdd((unsigned long long*)&st->wave_steps, (unsigned long long)wc.wave_steps);
         atomicAdd((unsigned long long*)&st->wave_walks, (unsigned long long)wc.wave_walks);
+        atomicAdd((unsigned long long*)&st->list_steps, (unsigned long long)v[9]);
+        atomicAdd((unsigned long long*)&st->wave_lists, (unsigned long long)wc.wave_lists);
+        atomicAdd((unsigned long long*)&st->wave_list_evals, (unsigned long long)wc.wave_list_evals);
     }
 }
 
@@ -907,6 +932,86 @@ __global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, floa
     if (lane == 0) *out = make_float4(acc.best, __builtin_bit_cast(float, acc.bid), acc.lb_key, acc.second);
 }
 
+// A march step on the nearest-candidate grid (kernels.hpp CandidateGrid; built at upload, grid.hip) instead of a
+// tree walk.  Every marching lane looks up its point's cell; a cell with a list names, as a 32-bit mask into its
+// brick's list of primitive ids, EVERY primitive that can attain or tie for the minimum anywhere in the cell, so
+// evaluating those -- with the same leaf arithmetic, in any order, under the same (distance, later index) rule --
+// gives the lane the result the exhaustive walk would.  The evaluation is wave-uniform like the walk's: the lanes'
+// masks are OR-ed per brick, each set bit's record arrives by scalar load and is evaluated for all 64 lanes (a
+// lane sees a superset of its own list, which cannot change its minimum).  ~6 primitive evaluations per pass
+// against ~30 box tests + ~4 evaluations for a walk on the bench frame.  What the lane keeps for certifying its
+// next steps: `second` over everything evaluated, and the cell's lower bound on everything not in its list.
+// Returns false (and touches nothing) when no marching lane has a list: the caller walks.
+template <int MODE, bool COUNT>
+__device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py, float pz, float mg, bool active, uint32_t lane,
+                                          float& best, uint32_t& bid, float& budget, bool& adv, WaveCounters& wc) {
+    if constexpr (MODE == SDFGPU_BOUNDS_OBB) return false;
+    if (T.gblock == nullptr) return false;
+    const f32x16 G = load_rec64_s48(T.gblock, 0u);   // GridBlock: lo[3], inv_cell[3], n[3], n[0]/4, n[1]/4, bricks_off
+    // cell of the point: floor((p - lo) / cell) per axis, out-of-range and non-numbers fail the unsigned compare
+    const float gx = __builtin_fminf(__builtin_fmaxf((px - G[0]) * G[3], -1.f), 65536.f);
+    const float gy = __builtin_fminf(__builtin_fmaxf((py - G[1]) * G[4], -1.f), 65536.f);
+    const float gz = __builtin_fminf(__builtin_fmaxf((pz - G[2]) * G[5], -1.f), 65536.f);
+    const uint32_t ix = (uint32_t)(int)__builtin_floorf(gx), iy = (uint32_t)(int)__builtin_floorf(gy), iz = (uint32_t)(int)__builtin_floorf(gz);
+    const bool in = ((uint32_t)active & (uint32_t)(ix < rec_bits(G[6])) & (uint32_t)(iy < rec_bits(G[7])) & (uint32_t)(iz < rec_bits(G[8]))) != 0u;
+    const uint32_t bi = ((iz >> 2) * rec_bits(G[10]) + (iy >> 2)) * rec_bits(G[9]) + (ix >> 2);
+    // both tables live in the block's own allocation: cells right behind it, brick ids at bricks_off
+    const char* __restrict__ gbase = reinterpret_cast<const char*>(T.gblock);
+    const uint32_t bricks_off = rec_bits(G[11]);
+    GridCell gc{0u, 0.f};
+    if (in) gc = *reinterpret_cast<const GridCell*>(gbase + sizeof(GridBlock) +
+                                                    (size_t)(((bi << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)) << 3));
+    const bool has_list = gc.mask != 0u;
+    // brick of a lane that still waits for its brick's round; lanes without a list wait for none
+    uint32_t bw = has_list ? bi : 0xFFFFFFFFu;
+    unsigned long long pend = __builtin_amdgcn_ballot_w64(bw != 0xFFFFFFFFu);
+    if (pend == 0ull) return false;
+    if constexpr (COUNT) { wc.wave_lists += 1; wc.lane_list_steps += has_list ? 1u : 0u; }
+    AccTracked acc{best, bid, __builtin_inff(), __builtin_inff()};
+    // Neighbouring bricks share most of their candidates, and the lanes of a wavefront stand in two or three bricks:
+    // lane k of `done` keeps the k-th primitive this pass has evaluated, and an id found there is not evaluated again
+    // (12.3 -> ~6 evaluations per pass on the bench frame).
+    uint32_t done = 0xFFFFFFFFu, n_done = 0;
+    do {   // one round per brick the listed lanes stand in (2-3 on the bench frame)
+        const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)__builtin_ctzll(pend));
+        // the brick's id list: ONE vector load (lane j takes entry j), entries then come by v_readlane -- a scalar
+        // load per entry put two dependent memory round trips in front of every evaluation
+        const uint32_t vids = *reinterpret_cast<const uint32_t*>(gbase + (bricks_off + sb * (GRID_BRICK_IDS * 4u) + ((lane & (GRID_BRICK_IDS - 1u)) << 2)));
+        const bool mine = bw == sb;
+        uint32_t m = __builtin_amdgcn_readfirstlane(__ockl_wfred_or_u32(mine ? gc.mask : 0u));
+        bw = mine ? 0xFFFFFFFFu : bw;
+        while (m != 0u) {
+            const uint32_t b = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)vids, (int)b);
+            if (__builtin_amdgcn_ballot_w64(done == id) != 0ull) continue;
+            done = (lane == n_done) ? id : done;
+            n_done += 1;
+            const f32x16 L = load_rec64_s48(T.leaf, id);
+            acc.offer(leaf_eval_rec(L, px, py, pz), id);
+            if constexpr (COUNT) {
+                wc.wave_list_evals += 1;
+                const uint32_t want = (has_list && bi == sb && ((gc.mask >> b) & 1u)) ? 1u : 0u;
+                if (rec_bits(L[15]) == SDF_PRIM_SPHERE) { wc.lane_sphere += has_list ? 1u : 0u; wc.lane_sphere_needed += want; }
+                else { wc.lane_box += has_list ? 1u : 0u; wc.lane_box_needed += want; }
+            }
+        }
+        pend = __builtin_amdgcn_ballot_w64(bw != 0xFFFFFFFFu);
+    } while (pend != 0ull);
+    // (the lane mask of "has a list" is formed again here rather than kept in an SGPR pair across the rounds: the
+    // march kernel sits one SGPR below the limit of its eighth wavefront per SIMD)
+    uint32_t gm = gc.mask;
+    asm volatile("" : "+v"(gm));
+    const bool listed = gm != 0u;
+    best = listed ? acc.best : best;
+    bid = listed ? acc.bid : bid;
+    // everything evaluated other than the winner is >= second; everything not in the lane's own list is >= the cell's bound
+    const float lb = __builtin_fminf(gc.lb, acc.second) - mg;
+    budget = listed ? lb : budget;
+    adv = listed;
+    return true;
+}
+
 template <int MODE, bool COUNT, bool FIRST, bool FAR>
 __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_camera cam, uint32_t width, uint32_t height,
                                                           sdfgpu_march_params mp, uint32_t tile_first,
@@ -998,7 +1103,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     const float ext = T.skip_ext;
     WaveCounters wc;
     uint32_t s = pa.step_begin;                  // this lane's step index (lanes no longer share one)
-    uint32_t n_walks = 0, n_cheap = 0;
+    uint32_t n_walks = 0, n_cheap = 0, n_lists = 0;
     // Lane state as data, not control flow: 0 = marching, 1 = hit, 2 = ended without a hit (left the
     // scene, off the image, not a ray).  The loop body is straight-line selects; the only branches are
     // wave-uniform (walk or not).
@@ -1040,8 +1145,13 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         if (cheap) {
             adv = certified;   // the others hold their position
             n_cheap += 1;
+        } else if (list_pass<MODE, COUNT>(T, px, py, pz, mg, active, lane, best, bid, budget, adv, wc)) {
+            // no marching lane can certify, but some stand in a grid cell with a candidate list: those lanes took
+            // their step on the list (list_pass); the others (outside the grid, cells without a list) hold their
+            // position until nobody can step otherwise, then the wavefront walks for them
+            n_lists += 1;
         } else {
-            // no marching lane can certify: one walk for all of them
+            // no marching lane can certify or has a list: one walk for all of them
             const unsigned long long dmask = m_active;
             AccTracked acc{best, bid, __builtin_inff(), __builtin_inff()};
             bool shared = false;
@@ -1104,7 +1214,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     if constexpr (FIRST) {
         if (pa.tile_cost && lane == 0) {
             // cost of the tile for the next frame's longest-first order: walks dominate, certified steps are ~1/16 of one
-            const uint32_t ran = n_walks + (n_cheap >> 4);
+            const uint32_t ran = n_walks + (n_lists >> 1) + (n_cheap >> 4);
             pa.tile_cost[slot >> 6] = ran < 255u ? ran : 255u;
         }
     }
@@ -1583,6 +1693,7 @@ static TreeView make_view(const DeviceTree& d, size_t prefetch_beyond = 4u << 20
     v.lip = d.lipschitz;
     v.bscale = d.box_scale;
     v.inv_bscale = 1.0f / d.box_scale;
+    v.gblock = d.grid.cells ? d.grid.block : nullptr;
     static const int forced = [] { const char* e = std::getenv("SDFGPU_PREFETCH"); return e ? std::atoi(e) : -1; }();
     v.xcd = 0;   // set by query_grid for the query kernels
     v.prefetch = forced >= 0 ? (uint32_t)(forced != 0) : (uint32_t)((size_t)d.n_leaf * (sizeof(GpuLeaf) + sizeof(GpuInner)) > prefetch_beyond);

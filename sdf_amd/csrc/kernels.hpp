@@ -8,8 +8,44 @@
 
 namespace sdfgpu {
 
+// Nearest-candidate grid (grid.hip): a uniform grid of cells over the padded scene box, cells grouped into
+// bricks of 4 x 4 x 4.  For a cell with centre c and (inflated) half diagonal r, every primitive that can be
+// the nearest one -- or tie for it -- at ANY point of the cell has value(c) <= min value(c) + 2 lip r + M (leaf
+// values are lip-Lipschitz, M covers their rounding), so that short candidate list decides a query anywhere in
+// the cell without a tree walk.  A brick keeps the union of its cells' lists (at most 32 primitive ids); a
+// cell keeps a 32-bit mask into its brick's list and `lb` = a lower bound, at any point of the cell, on every
+// primitive NOT in its list.  mask == 0: the cell has no list (too many candidates): walk.
+struct GridCell {
+    uint32_t mask;
+    float lb;
+};
+constexpr uint32_t GRID_BRICK_IDS = 32;   // entries of a brick's candidate list (one mask bit each)
+constexpr uint32_t GRID_CELL_K = 16;      // candidates looked at per cell (the K of the k-nearest query that builds it)
+struct CandidateGrid {
+    // ONE allocation: [GridBlock | cells | brick ids].  The march addresses both tables relative to `block` (a
+    // pointer pair it holds anyway), which is worth two SGPRs it does not have to spare.
+    GridCell* cells = nullptr;      // [bricks][64], cell (x, y, z) of a brick at (z & 3) << 4 | (y & 3) << 2 | (x & 3)
+    uint32_t* brick_ids = nullptr;  // [bricks][GRID_BRICK_IDS]
+    float lo[3] = {0.f, 0.f, 0.f};
+    float inv_cell[3] = {0.f, 0.f, 0.f};
+    uint32_t n[3] = {0, 0, 0};      // cells per axis (multiples of 4)
+    uint64_t bytes = 0;
+    void* block = nullptr;          // GridBlock in HBM: what the march reads (one scalar load per list pass)
+};
+// The 64 bytes the march kernel fetches at the start of a list pass.
+struct alignas(64) GridBlock {
+    float lo[3];
+    float inv_cell[3];
+    uint32_t n[3];
+    uint32_t nbx, nby;              // bricks per axis (x, y)
+    uint32_t bricks_off;            // byte offset of the brick id table from this block (the cells follow the block directly)
+    uint32_t pad[4];
+};
+static_assert(sizeof(GridBlock) == 64, "GridBlock is one 64-byte scalar load");
+
 // Device-resident compact tree (pointers into HBM).
 struct DeviceTree {
+    CandidateGrid grid;                 // cells == nullptr: none (general path, OBB / NONE bounds, tiny trees, switched off)
     GpuLeaf* leaf = nullptr;
     GpuInner* inner = nullptr;
     GpuInnerObb* inner_obb = nullptr;
@@ -79,6 +115,13 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
                          const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count,
                          bool row_major, const RenderScratch& rs, const uint32_t* pass_bounds, uint32_t n_bounds,
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s);
+
+// Builds the candidate grid of a resident tree (AABB / BVH bounds) on `s`: cell centres -> k-nearest query
+// (the library's own kNN kernel, K = GRID_CELL_K) -> per-brick union.  `d.grid` must describe the geometry (lo,
+// inv_cell, n) and point at cells / brick_ids sized for it; temp holds the per-chunk centres and rows.
+size_t grid_temp_bytes(uint32_t chunk_bricks);
+hipError_t build_candidate_grid(const DeviceTree& d, float cell_radius_inflated, float list_margin, void* temp,
+                                uint32_t chunk_bricks, hipStream_t s);
 
 // MINDIST / MAXDIST of one box at n points (faux_shader.rs:39-58, all four lanes).
 hipError_t launch_box_bounds(const SdfBoundingBoxBlock* d_box, const float* d_pts_xyzw, uint32_t n, float* d_min,

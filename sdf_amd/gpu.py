@@ -129,6 +129,10 @@ class SdfGpu:
     def set_tile_order(self, enabled):
         self.set_option(_ffi.OPT_TILE_ORDER, 1 if enabled else 0)
 
+    def set_candidate_grid(self, enabled):
+        """Whether the NEXT upload also builds the nearest-candidate grid (default on)."""
+        self.set_option(_ffi.OPT_CANDIDATE_GRID, 1 if enabled else 0)
+
     def set_skip_extension(self, value):
         """0 (default): no widening of the search radius; < 0: half the mean primitive size."""
         self.set_option(_ffi.OPT_SKIP_EXTENSION, value)

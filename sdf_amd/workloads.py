@@ -116,6 +116,7 @@ FLOP_SPHERE = 27     # 3x4 mat-vec (18) + length3 (6) + sub + better-than test (
 FLOP_BOX = 39        # 3x4 mat-vec (18) + box formula (19) + better-than test (2)
 FLOP_QUERY = 16      # ray point (6) + margin (7) + hit / t_max tests and t update (3)
 FLOP_NORMAL_TAP = 6  # 3 point offsets + 3 accumulations per tap (leaf evals counted as sphere/box)
+FLOP_CELL = 9        # a march step decided on the candidate grid: cell of the point = 3 x (sub, mul, floor)
 
 
 def algorithmic_flops(stats: dict) -> int:
@@ -123,7 +124,7 @@ def algorithmic_flops(stats: dict) -> int:
     (lane-level: work done for lanes that were alive)."""
     per_step = max(stats["steps"], stats["queries"])   # render: every march step; nearest: every query
     return (stats["inner_visits"] * FLOP_INNER + stats["sphere_evals"] * FLOP_SPHERE
-            + stats["box_evals"] * FLOP_BOX + per_step * FLOP_QUERY)
+            + stats["box_evals"] * FLOP_BOX + per_step * FLOP_QUERY + stats.get("list_steps", 0) * FLOP_CELL)
 
 
 def algorithmic_flops_needed(stats: dict) -> int:
@@ -132,4 +133,4 @@ def algorithmic_flops_needed(stats: dict) -> int:
     lanes need; lanes that only ride along are not counted here)."""
     per_step = max(stats["steps"], stats["queries"])
     return (stats["inner_needed"] * FLOP_INNER + stats["sphere_needed"] * FLOP_SPHERE
-            + stats["box_needed"] * FLOP_BOX + per_step * FLOP_QUERY)
+            + stats["box_needed"] * FLOP_BOX + per_step * FLOP_QUERY + stats.get("list_steps", 0) * FLOP_CELL)

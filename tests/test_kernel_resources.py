@@ -63,7 +63,7 @@ def test_no_kernel_spills(report):
 ])
 def test_production_kernels_keep_eight_wavefronts(report, parts):
     for name, r in _pick(report, *parts).items():
-        assert r["TotalSGPRs"] <= 96, (name, r)
+        assert r["TotalSGPRs"] <= 100, (name, r)   # the compiler's own occupancy figure drops to 7 at 101 (measured, round 3)
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 64, (name, r)
         assert r["Occupancy"] == 8, (name, r)
 

@@ -299,6 +299,221 @@ static void walk_wide(Lane* L, Stats& st) {
     st.by_drive_inner[ndrive] += st.wave_inner - inner0;
 }
 
+// ---- SIM_GRID: nearest-candidate grid --------------------------------------------------------------------
+// A uniform grid over the scene box (scaled by SIM_GRID_PAD).  For a cell with centre c and half diagonal r every
+// primitive that can be the nearest one at ANY point of the cell has d_i(c) <= d_min(c) + 2 r (values are
+// 1-Lipschitz), so the cell keeps that candidate list (at most SIM_GRID_K entries, else "overflow": walk) and
+// lb = d_min(c) + r, a lower bound at any point of the cell on every primitive NOT in the list.
+struct Grid {
+    int n = 0, K = 8;
+    float lo[3], inv[3], cell[3], r = 0;
+    std::vector<uint32_t> off;     // n^3 + 1
+    std::vector<uint32_t> idx;
+    std::vector<float> lb;         // per cell; < 0: overflow
+} G;
+
+static void collect(uint32_t ref, float cx, float cy, float cz, float R, std::vector<std::pair<float, uint32_t>>& out) {
+    if (ref & REF_LEAF) {
+        uint32_t id = ref & REF_INDEX;
+        float d = leaf_eval(T.leaves[id], cx, cy, cz);
+        if (d <= R) out.push_back({d, id});
+        return;
+    }
+    const GpuInner& N = T.inner[ref];
+    const float sc = T.box_scale;
+    float Rs = std::fmax(R, 0.f) * sc;
+    Rs = Rs * Rs * 1.001f;
+    if (aabb_d2(N.c0, N.h0, cx * sc, cy * sc, cz * sc) <= Rs) collect(N.ref0, cx, cy, cz, R, out);
+    if (aabb_d2(N.c1, N.h1, cx * sc, cy * sc, cz * sc) <= Rs) collect(N.ref1, cx, cy, cz, R, out);
+}
+static float nearest_d(uint32_t ref, float cx, float cy, float cz, float best) {
+    if (ref & REF_LEAF) return std::fmin(best, leaf_eval(T.leaves[ref & REF_INDEX], cx, cy, cz));
+    const GpuInner& N = T.inner[ref];
+    const float sc = T.box_scale;
+    float k0 = aabb_d2(N.c0, N.h0, cx * sc, cy * sc, cz * sc), k1 = aabb_d2(N.c1, N.h1, cx * sc, cy * sc, cz * sc);
+    uint32_t a = N.ref0, b = N.ref1;
+    if (k1 < k0) { std::swap(a, b); std::swap(k0, k1); }
+    auto thr = [&](float bst) { float bp = std::fmax(bst, 0.f) * sc; return bp * bp * 1.001f; };
+    if (k0 <= thr(best)) best = nearest_d(a, cx, cy, cz, best);
+    if (k1 <= thr(best)) best = nearest_d(b, cx, cy, cz, best);
+    return best;
+}
+static void build_grid(int n, int K, float pad) {
+    G.n = n; G.K = K;
+    for (int a = 0; a < 3; ++a) {
+        float c = 0.5f * (T.info.scene_lo[a] + T.info.scene_hi[a]), h = 0.5f * (T.info.scene_hi[a] - T.info.scene_lo[a]) * pad;
+        G.lo[a] = c - h; G.cell[a] = 2 * h / n; G.inv[a] = 1.0f / G.cell[a];
+    }
+    G.r = 0.5f * std::sqrt(G.cell[0] * G.cell[0] + G.cell[1] * G.cell[1] + G.cell[2] * G.cell[2]);
+    size_t nc = (size_t)n * n * n;
+    std::vector<std::vector<uint32_t>> lists(nc);
+    G.lb.assign(nc, -1.f);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t c = 0; c < nc; ++c) {
+        int x = c % n, y = (c / n) % n, z = c / ((size_t)n * n);
+        float cx = G.lo[0] + (x + 0.5f) * G.cell[0], cy = G.lo[1] + (y + 0.5f) * G.cell[1], cz = G.lo[2] + (z + 0.5f) * G.cell[2];
+        float dmin = nearest_d(T.root_ref, cx, cy, cz, INFINITY);
+        std::vector<std::pair<float, uint32_t>> cand;
+        collect(T.root_ref, cx, cy, cz, dmin + 2.0f * G.r * 1.001f + 1e-3f, cand);
+        if ((int)cand.size() > K) continue;   // overflow: lb stays < 0
+        std::sort(cand.begin(), cand.end());
+        for (auto& e : cand) lists[c].push_back(e.second);
+        G.lb[c] = dmin + G.r;
+    }
+    G.off.assign(nc + 1, 0);
+    for (size_t c = 0; c < nc; ++c) G.off[c + 1] = G.off[c] + (uint32_t)lists[c].size();
+    G.idx.resize(G.off[nc]);
+    size_t over = 0; uint64_t hist[33] = {0};
+    for (size_t c = 0; c < nc; ++c) {
+        std::copy(lists[c].begin(), lists[c].end(), G.idx.begin() + G.off[c]);
+        if (G.lb[c] < 0) over++; else hist[std::min<size_t>(32, lists[c].size())]++;
+    }
+    printf("grid %d^3 cells, cell %.2f, r %.2f, K %d: overflow cells %.3f, mean list %.2f, bytes %.1f MB\n", n, G.cell[0], G.r, K,
+           (double)over / nc, (double)G.idx.size() / (nc - over), (nc * 8.0 + G.idx.size() * 4.0) / 1e6);
+    {   // bricks of 4^3 cells: union of the cells' lists
+        const int B = 4, nb = n / B, cap = getenv("SIM_BRICK_CAP") ? atoi(getenv("SIM_BRICK_CAP")) : 32;
+        size_t bover = 0, cells_lost = 0; double usum = 0;
+        for (int bz = 0; bz < nb; ++bz) for (int by = 0; by < nb; ++by) for (int bx = 0; bx < nb; ++bx) {
+            std::vector<uint32_t> u;
+            int good = 0;
+            for (int z = 0; z < B; ++z) for (int y = 0; y < B; ++y) for (int x = 0; x < B; ++x) {
+                size_t c = ((size_t)(bz * B + z) * n + (by * B + y)) * n + (bx * B + x);
+                if (G.lb[c] < 0) continue;
+                good++;
+                u.insert(u.end(), G.idx.begin() + G.off[c], G.idx.begin() + G.off[c + 1]);
+            }
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            usum += u.size();
+            if ((int)u.size() > cap) {
+                bover++; cells_lost += good;
+                for (int z = 0; z < B; ++z) for (int y = 0; y < B; ++y) for (int x = 0; x < B; ++x)
+                    G.lb[((size_t)(bz * B + z) * n + (by * B + y)) * n + (bx * B + x)] = -1.f;
+            }
+        }
+        printf("  bricks %d^3: mean union %.2f, bricks over the cap of %d: %.4f (cells lost %.4f)\n", nb, usum / ((double)nb * nb * nb), cap,
+               (double)bover / ((double)nb * nb * nb), (double)cells_lost / nc);
+    }
+    printf("  list length histogram:");
+    for (int i = 0; i <= 32; ++i) if (hist[i]) printf(" %d:%.3f", i, (double)hist[i] / nc);
+    printf("\n");
+}
+static inline long grid_cell(float px, float py, float pz) {
+    float fx = (px - G.lo[0]) * G.inv[0], fy = (py - G.lo[1]) * G.inv[1], fz = (pz - G.lo[2]) * G.inv[2];
+    if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx < G.n && fy < G.n && fz < G.n)) return -1;
+    return ((long)fz * G.n + (long)fy) * G.n + (long)fx;
+}
+
+struct GridStats {
+    uint64_t iters = 0, list_iters = 0, list_len_max_sum = 0, list_len_sum = 0, list_lanes = 0, cert_lanes = 0, walk_lanes = 0,
+             outside = 0, overflow = 0, uniq_sum = 0, cells_sum = 0, cell_len_sum = 0, bricks_sum = 0;
+    void add(const GridStats& o) {
+        iters += o.iters; list_iters += o.list_iters; list_len_max_sum += o.list_len_max_sum; list_len_sum += o.list_len_sum;
+        list_lanes += o.list_lanes; cert_lanes += o.cert_lanes; walk_lanes += o.walk_lanes; outside += o.outside; overflow += o.overflow;
+        uniq_sum += o.uniq_sum; cells_sum += o.cells_sum; cell_len_sum += o.cell_len_sum; bricks_sum += o.bricks_sum;
+    }
+} g_gs;
+
+// March step with the grid: certified lanes step on their seed; the others step on their cell's list; lanes
+// whose point has no list (outside the grid, overflow cell) wait until no lane of the wave can step otherwise,
+// then the wave walks for them.  policy 1: lanes with a list also wait while some lane can certify (deferral).
+static void wave_step_grid(Lane* L, Stats& st, GridStats& gs, int policy) {
+    int nalive = 0, ncert = 0, nlist = 0, nwalk = 0;
+    long cellof[64];
+    for (int i = 0; i < 64; ++i) {
+        Lane& l = L[i];
+        l.drive = false; l.certified = false;
+        l.best = INFINITY; l.bid = SDF_NO_PRIM; l.second = INFINITY; l.lbk = INFINITY;
+        cellof[i] = -1;
+        if (!l.alive) continue;
+        nalive++;
+        l.px = ox + l.dx * l.t; l.py = oy + l.dy * l.t; l.pz = oz + l.dz * l.t;
+        l.mg = 3.0e-6f * g_lip * (std::fabs(l.px) + std::fabs(l.py) + std::fabs(l.pz) + T.margin_T);
+        if (l.last != SDF_NO_PRIM) {
+            l.best = leaf_eval(T.leaves[l.last], l.px, l.py, l.pz);
+            l.bid = l.last;
+            l.certified = (l.best + 2.0f * l.mg) < l.budget;
+        }
+        if (l.certified) { ncert++; continue; }
+        long c = grid_cell(l.px, l.py, l.pz);
+        if (c >= 0 && G.lb[c] >= 0) { cellof[i] = c; nlist++; }
+        else { l.drive = true; nwalk++; if (c < 0) gs.outside++; else gs.overflow++; }
+    }
+    if (nalive == 0) return;
+    st.wave_steps++;
+    gs.iters++;
+    const bool lists_go = nlist > 0 && !(policy == 1 && ncert > 0);
+    const bool do_walk = nwalk > 0 && ncert == 0 && nlist == 0;
+    if (do_walk) {
+        st.wave_walks++;
+        st.lane_walks += nwalk;
+        for (int i = 0; i < 64; ++i) L[i].sid = SDF_NO_PRIM;
+        walk(L, st);
+    }
+    if (lists_go) {
+        gs.list_iters++;
+        uint32_t mx = 0;
+        std::vector<uint32_t> uniq;
+        for (int i = 0; i < 64; ++i) {
+            if (cellof[i] < 0) continue;
+            Lane& l = L[i];
+            const long c = cellof[i];
+            const uint32_t n = G.off[c + 1] - G.off[c];
+            mx = std::max(mx, n);
+            gs.list_len_sum += n; gs.list_lanes++;
+            l.best = INFINITY; l.bid = SDF_NO_PRIM; l.second = INFINITY;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t id = G.idx[G.off[c] + j];
+                uniq.push_back(id);
+                const float d = leaf_eval(T.leaves[id], l.px, l.py, l.pz);
+                const bool b = is_better(d, id, l.best, l.bid);
+                const float loser = b ? l.best : d;
+                if (loser < l.second) l.second = loser;
+                if (b) { l.best = d; l.bid = id; }
+            }
+            l.budget = std::fmin(l.second, G.lb[c]) - 2.f * l.mg;
+        }
+        std::sort(uniq.begin(), uniq.end());
+        gs.uniq_sum += std::unique(uniq.begin(), uniq.end()) - uniq.begin();
+        std::vector<long> cs;
+        for (int i = 0; i < 64; ++i) if (cellof[i] >= 0) cs.push_back(cellof[i]);
+        std::sort(cs.begin(), cs.end());
+        cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+        gs.cells_sum += cs.size();
+        for (long c : cs) gs.cell_len_sum += G.off[c + 1] - G.off[c];
+        std::vector<long> bs;
+        for (long c : cs) { long x = c % G.n, y = (c / G.n) % G.n, z = c / ((long)G.n * G.n); bs.push_back(((z / 4) * (G.n / 4) + y / 4) * (G.n / 4) + x / 4); }
+        std::sort(bs.begin(), bs.end());
+        bs.erase(std::unique(bs.begin(), bs.end()), bs.end());
+        gs.bricks_sum += bs.size();
+        gs.list_len_max_sum += mx;
+    }
+    for (int i = 0; i < 64; ++i) {
+        Lane& l = L[i];
+        if (!l.alive) continue;
+        bool adv;
+        if (l.certified) adv = true;
+        else if (cellof[i] >= 0) adv = lists_go;
+        else adv = do_walk;
+        if (!adv) continue;
+        if (l.certified) gs.cert_lanes++;
+        if (do_walk && l.drive) {
+            gs.walk_lanes++;
+            l.budget = std::fmin(std::sqrt(l.lbk) / T.box_scale * 0.9996f, l.second) - l.mg;
+        }
+        l.steps++;
+        st.lane_steps++;
+        l.last = l.bid;
+        if (l.best < mp.eps_hit) { l.hit = true; l.alive = false; }
+        else {
+            l.t = l.t + l.best;
+            l.budget = (l.budget - std::fabs(l.best) * g_lip) - l.mg;
+            if (l.t > mp.t_max) l.alive = false;
+        }
+        if (l.alive && l.steps >= mp.max_steps) l.alive = false;
+    }
+}
+
 // One march step of a wave.  defer_thr > 0: lanes that cannot certify wait (do not advance) while fewer than
 // defer_thr of them are waiting and some certified lane can still advance.
 static void wave_step(Lane* L, Stats& st, int defer_thr, std::vector<int>* finished) {
@@ -396,6 +611,9 @@ int main(int argc, char** argv) {
     mp = {128, 1e-3f, 0.f, 6.0f * L, 1e-4f, 0};
     ox = cam.eye[0]; oy = cam.eye[1]; oz = cam.eye[2];
 
+    const int grid_n = getenv("SIM_GRID") ? atoi(getenv("SIM_GRID")) : 0;
+    const int grid_policy = getenv("SIM_GRID_POLICY") ? atoi(getenv("SIM_GRID_POLICY")) : 0;
+    if (grid_n > 0) build_grid(grid_n, getenv("SIM_GRID_K") ? atoi(getenv("SIM_GRID_K")) : 8, getenv("SIM_GRID_PAD") ? atof(getenv("SIM_GRID_PAD")) : 1.0f);
     const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th, n_tiles = tiles_x * tiles_y;
     Stats gst;
     std::vector<double> wave_cost;   // per-wave VALU (critical path)
@@ -404,6 +622,7 @@ int main(int argc, char** argv) {
 #pragma omp parallel for schedule(dynamic, 16)
         for (uint32_t t = 0; t < n_tiles; ++t) {
             Stats st;
+            GridStats gs;
             Lane Ls[64];
             for (int i = 0; i < 64; ++i) init_ray(Ls[i], (t % tiles_x) * tw + i % tw, (t / tiles_x) * th + i / tw);
             double c0 = st.valu();
@@ -411,11 +630,11 @@ int main(int argc, char** argv) {
                 bool any = false;
                 for (auto& l : Ls) any |= l.alive;
                 if (!any) break;
-                wave_step(Ls, st, defer, nullptr);
+                if (grid_n > 0) wave_step_grid(Ls, st, gs, grid_policy); else wave_step(Ls, st, defer, nullptr);
             }
-            wave_cost[t] = st.valu() - c0;
+            wave_cost[t] = st.valu() - c0 + 30.0 * gs.list_iters + 55.0 * gs.list_len_max_sum;
 #pragma omp critical
-            gst.add(st);
+            { gst.add(st); g_gs.add(gs); }
         }
     } else if (strat == "refill") {
         // persistent waves, each owning a contiguous strip of `strip` tiles; dead lanes are refilled from the strip's
@@ -454,6 +673,18 @@ int main(int argc, char** argv) {
            st.wave_inner, st.wave_leaf, st.lane_steps, st.lane_walks);
     printf("inner/walk %.1f lane_inner/lane_walk %.1f needed/lane_walk %.1f  VALU est %.3fe9\n", (double)st.wave_inner / st.wave_walks,
            (double)st.lane_inner / st.lane_walks, (double)st.lane_needed / st.lane_walks, st.valu() / 1e9);
+    if (grid_n > 0) {
+        const GridStats& g = g_gs;
+        printf("grid: iterations %lu, with a list pass %lu (max list length per pass %.2f, mean per lane %.2f, unique prims per pass %.2f)\n", g.iters,
+               g.list_iters, (double)g.list_len_max_sum / std::max<uint64_t>(1, g.list_iters), (double)g.list_len_sum / std::max<uint64_t>(1, g.list_lanes),
+               (double)g.uniq_sum / std::max<uint64_t>(1, g.list_iters));
+        printf("grid: distinct cells per list pass %.2f, sum of their list lengths %.2f, distinct bricks %.2f\n", (double)g.cells_sum / std::max<uint64_t>(1, g.list_iters),
+               (double)g.cell_len_sum / std::max<uint64_t>(1, g.list_iters), (double)g.bricks_sum / std::max<uint64_t>(1, g.list_iters));
+        printf("grid: lane-steps certified %lu, by list %lu, by walk %lu; waits outside the grid %lu, in overflow cells %lu\n", g.cert_lanes,
+               g.list_lanes, g.walk_lanes, g.outside, g.overflow);
+        printf("grid: VALU est %.3fe9 (walk part %.3fe9 + lists %.3fe9)\n", (st.valu() + 30.0 * g.list_iters + 55.0 * g.list_len_max_sum) / 1e9,
+               st.valu() / 1e9, (30.0 * g.list_iters + 55.0 * g.list_len_max_sum) / 1e9);
+    }
     printf("box tests %lu (%.2f per node visit)  stack pushes %lu\n", st.box_tests, (double)st.box_tests / st.wave_inner, st.pushes);
     printf("leading single-child chain: %.2f inner visits per walk\n", (double)st.chain_inner / st.wave_walks);
     if (strat == "tile")
