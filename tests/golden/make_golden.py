@@ -47,7 +47,40 @@ def single_sphere():
     return b.finalize().expanded().make_buffer(), 10.0
 
 
+def pca_inner_scene():
+    """What the crate's own SdfBoundingBox::merge writes (obb.rs:183-185): every merged box carries a PCA
+    trans_inverse that re-bases the point handed to its children (SURVEY C-3, 7.4 'one with non-identity
+    internal trans_inverse')."""
+    n = 12
+    return S.random_scene(n, 0x601D0C3, opts={"pca_trans_inverse": True}).expanded().make_buffer(), S.default_extent(n)
+
+
+def clone_scene():
+    """Live primitives mixed with one-slot CAA clones (elements.rs:215-262): as the flat query is written a clone
+    subtree contributes +inf (faux_shader.rs:90; SURVEY A-6, 7.4 'one with a CAA-clone')."""
+    rng = np.random.default_rng(0xC10E)
+    L = 12.0
+
+    def prim():
+        e = S.SdfSphere(float(rng.uniform(0.5, 2.0))) if rng.random() < 0.5 else S.SdfBox(tuple(float(v) for v in rng.uniform(0.5, 2.0, 3)))
+        return S.SdfBuilder.primitive(e).transform(S.Transform.from_translation(tuple(float(v) for v in rng.uniform(-L, L, 3))))
+
+    parts = [prim() for _ in range(9)]
+    for at in (2, 5, 9):
+        parts.insert(at, prim().operation(S.SdfCaaClone((6, 6, 6), (-2, -2, -2), (2, 2, 2))))
+    b = parts[0].operation(S.SdfUnion(0.0))
+    for x in parts[1:]:
+        b = b.with_(x)
+    return b.finalize().expanded().make_buffer(), L
+
+
+# bounds modes a fixture can be uploaded with (a buffer with re-basing internal nodes takes AUTO / NONE only)
+ALL_BOUNDS = [1, 2, 3, 4]
+BOUNDS_OK = {"pca_inner_12": [0, 3]}
+
 SCENES = {
+    "pca_inner_12": pca_inner_scene,
+    "clone_mix_12": clone_scene,
     "single_sphere": single_sphere,
     "duplicates_tie": duplicate_scene,
     "random_2": lambda: (S.random_scene_buffer(2, 0x601D0002), S.default_extent(2)),
@@ -70,6 +103,8 @@ def main():
         d2, i2 = O.nearest(buf, pts, O.MODE_FAUX)
         assert np.array_equal(d.view(np.uint32), d2.view(np.uint32))
         assert np.array_equal(i, i2) or name == "duplicates_tie"
+        if name == "clone_mix_12":
+            assert len(set(i.tolist())) > 3 and buf.downtree_buffer["op_code"][buf.downtree_buffer["is_primitive"] == 0].max() == 1
         kd, ki = O.knn(buf, pts, 8)
         w, h = 24, 16
         cam = S.camera_look_at((0, 0, -2.5 * ext), (0, 0, 0), (0, 1, 0), math.pi / 4, w, h)
@@ -82,6 +117,7 @@ def main():
             cam=np.array(list(cam.eye) + list(cam.origin) + list(cam.du) + list(cam.dv), np.float32),
             march=np.array([mp.max_steps, mp.eps_hit, mp.t_min, mp.t_max, mp.normal_h], np.float64),
             wh=np.array([w, h]), hit=img["hit"], depth=img["depth"], normal=img["normal"], rprim=img["prim"],
+            bounds_ok=np.array(BOUNDS_OK.get(name, ALL_BOUNDS)),
         )
         print(name, buf.buffer_len, "nodes;", int(img["hit"].sum()), "hit pixels")
 

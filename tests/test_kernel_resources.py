@@ -16,6 +16,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sdf_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+_ASM_TEXT = None
 
 
 @pytest.fixture(scope="module")
@@ -29,6 +30,8 @@ def report(tmp_path_factory):
                                              os.path.join(CSRC, "kernels.hip"), "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
     assert r.returncode == 0, r.stderr[-2000:]
+    global _ASM_TEXT
+    _ASM_TEXT = out.read_text()
     kernels, cur = {}, None
     for line in r.stderr.splitlines():
         m = re.search(r"remark:\s+Function Name: (\S+)", line)
@@ -72,3 +75,33 @@ def test_obb_march_keeps_seven_wavefronts(report):
     # the OBB walk holds both children's 64-byte records in SGPRs (load_rec128): 7 wavefronts, not fewer
     for name, r in _pick(report, "render_pass_kernelILi2ELb0E").items():
         assert r["TotalSGPRs"] <= 112 and r["VGPRs"] <= 72, (name, r)
+
+
+# Instructions that read M0 without naming it (gfx9: LDS-DMA forms, GWS, message sends, relative moves).
+_IMPLICIT_M0 = re.compile(r"^\s*(s_sendmsg|s_sendmsghalt|ds_gws_\w+|s_movrel\w+|v_movrel\w+|\w+_load_lds_\w+|buffer_load_\w+\s.*\blds\b|ds_direct_\w+|v_interp_\w+)")
+
+
+def test_walk_blocks_m0_write_is_never_read_stale(report):
+    """The assembly walk writes M0 (lane select of v_writelane) and cannot list it as a clobber (a reserved
+    register to this compiler).  That is sound only while nothing reads M0 except the v_writelane that follows
+    the write: checked here on the generated code of every kernel -- each read of M0 is a v_writelane directly
+    behind a write of M0 (at most a wait state between them), and no instruction that reads M0 implicitly
+    exists at all, so a value of the compiler's own can never be what the block overwrote."""
+    assert _ASM_TEXT, "the report fixture keeps the assembly text"
+    lines = [l.split(";")[0].rstrip() for l in _ASM_TEXT.splitlines()]
+    code = [l for l in lines if l.strip() and not l.strip().startswith((".", "//")) and not l.strip().endswith(":")]
+    writes = reads = 0
+    for i, l in enumerate(code):
+        t = l.strip()
+        assert not _IMPLICIT_M0.match(t), f"instruction reading M0 implicitly: {t}"
+        if not re.search(r"\bm0\b", t):
+            continue
+        if re.match(r"s_mov_b32 m0,", t):
+            writes += 1
+            continue
+        # every other mention of m0 must be the lane select of a v_writelane fed by the write just before it
+        assert re.match(r"v_writelane_b32 v\d+, s\d+, m0$", t), f"unexpected use of m0: {t}"
+        prev = [c.strip() for c in code[max(0, i - 2):i]]
+        assert any(re.match(r"s_mov_b32 m0,", c) for c in prev) and all(re.match(r"(s_mov_b32 m0,|s_nop)", c) for c in prev[-1:]), (prev, t)
+        reads += 1
+    assert writes == reads and reads > 20, (writes, reads)   # one write per read: the walk's pushes, in every instantiation
