@@ -138,7 +138,7 @@ def cpu_baseline(buf, cam, mp, w, h, budget_s):
         stride = max(1, npix // cnt)
         cnt = min(cnt, (npix + stride - 1) // stride)
         t0 = time.perf_counter()
-        O.render(buf, cam, w, h, mp, mode=mode, threads=threads, pix_first=0, pix_count=cnt, pix_stride=stride)
+        O.render(buf, cam, w, h, mp, mode=mode, threads=threads, pix_first=0, pix_count=cnt, pix_stride=stride)   # `threads` as bound at call time
         return cnt, stride, time.perf_counter() - t0
 
     def sized(mode, pilot, share):
@@ -146,7 +146,7 @@ def cpu_baseline(buf, cam, mp, w, h, budget_s):
         want = int(min(npix, max(pilot, cnt / max(t, 1e-6) * budget_s * share)))
         return run(mode, want)
 
-    cnt, stride, t = sized(O.MODE_TUNED, 4096, 0.6)
+    cnt, stride, t = sized(O.MODE_TUNED, 4096, 0.5)
     out = {
         "value": cnt / t / 1e6,
         "unit": "Mrays/s",
@@ -155,7 +155,13 @@ def cpu_baseline(buf, cam, mp, w, h, budget_s):
         "sample": f"{cnt} rays (every {stride}th pixel of the same frame), oracle_render MODE_TUNED "
                   f"(C++ restatement, best-so-far pruning), {threads} threads, {t:.2f} s",
     }
-    cnt_f, stride_f, t_f = sized(O.MODE_FAUX_FAITHFUL, 128, 0.4)
+    # the same tuned port on ONE host thread (1 thread and all cores)
+    threads_all, threads = threads, 1
+    cnt1, stride1, t1 = sized(O.MODE_TUNED, 1024, 0.15)
+    threads = threads_all
+    out["one_thread_value"] = cnt1 / t1 / 1e6
+    out["one_thread_sample"] = f"{cnt1} rays (every {stride1}th pixel), oracle_render MODE_TUNED, 1 thread, {t1:.2f} s"
+    cnt_f, stride_f, t_f = sized(O.MODE_FAUX_FAITHFUL, 128, 0.25)
     out["faithful_value"] = cnt_f / t_f / 1e6
     out["faithful_sample"] = (f"{cnt_f} rays (every {stride_f}th pixel), faux_shader::nearest_neighbor as written "
                               f"(O(N) walk, 256-frame allocation per query), {threads} threads, {t_f:.2f} s")
@@ -433,6 +439,53 @@ def variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev):
     torch.cuda.synchronize()
     out["cold_frame_ms"] = (time.perf_counter() - t0) * 1e3
     g2.close()
+    # the other single-GPU frames of BASELINE.json (configs 2 and 4), same code, a few frames each, two in flight
+    for cfg in (2, 4):
+        wlx = W.CONFIGS[cfg]
+        wx, hx = wlx.width, wlx.height
+        gx = S.SdfGpu(dev.index)
+        infx = gx.upload_tree(W.scene(wlx))
+        camx, mpx = W.camera(wlx, wx, hx), W.march(wlx)
+        outs = [(torch.empty(wx * hx, dtype=torch.uint8, device=dev), torch.empty(wx * hx, dtype=torch.float32, device=dev),
+                 torch.empty(wx * hx * 3, dtype=torch.float32, device=dev), torch.empty(wx * hx, dtype=torch.int32, device=dev))
+                for _ in range(depth)]
+
+        def framex(kk):
+            o = outs[kk % depth]
+            gx.render_dev(camx, wx, hx, mpx, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), slots[kk % depth].stream.cuda_stream)
+
+        for kk in range(2 * depth):
+            framex(kk)
+        nfr = 40 if cfg == 2 else 12
+        msx = run(framex, nfr)
+        out[f"config{cfg}"] = {"value": wx * hx / msx / 1e3, "ms_per_step": msx, "unit": "Mrays/s", "frames": nfr,
+                               "note": f"{wlx.name}: {wx}x{hx}, {wlx.n_prims} primitives, one MI355X, {depth} frames in flight; "
+                                       f"resident tree + grid {infx.device_bytes / 1e6:.1f} MB ({int(infx.grid_cells)} grid cells)"}
+        del outs
+        gx.close()
+    # The same scene as the crate's own builder emits it: every merged box carries its PCA trans_inverse (obb.rs:183-185),
+    # so every level re-bases the point (faux_shader.rs:165,175).  Pruned since round 3 ("chain path": the library's
+    # hierarchy over the composed maps' world boxes, leaf values through the reference's one rounded mat-vec per level).
+    crate = S.random_scene(wl.n_prims, wl.seed, opts={"pca_trans_inverse": True}).expanded().make_buffer()
+    gc = S.SdfGpu(dev.index)
+    infc = gc.upload_tree(crate)
+
+    def crate_frame(kk):
+        sl = slots[kk % depth]
+        gc.render_dev(cam, w, h, mp, sl.o_hit.data_ptr(), sl.o_depth.data_ptr(), sl.o_normal.data_ptr(), sl.o_prim.data_ptr(), sl.stream.cuda_stream)
+
+    for kk in range(2 * depth):
+        crate_frame(kk)
+    msc = run(crate_frame, 20)
+    out["crate_buffer"] = {"value": npix / msc / 1e3, "ms_per_step": msc, "unit": "Mrays/s", "frames": 20,
+                           "ratio_to_identity_buffer_frame": msc / ms1,
+                           "bounds": {1: "aabb", 2: "obb", 3: "none", 4: "bvh"}[int(infc.bounds)], "identity_inner": int(infc.identity_inner),
+                           "note": f"{wl.name} built with pca_trans_inverse (the crate's literal merged boxes): chain path, {depth} frames in "
+                                   "flight; before round 3 such a buffer was walked exhaustively, O(nodes) per query"}
+    gc.close()
+    for kk in range(2 * depth):   # slots back to the headline scene's frame
+        frame(gpu, cam, slots[kk % depth])
+    torch.cuda.synchronize()
     # tree flatten (host builder's make_buffer) and upload (validate + SAH build + copy), per scene size
     out["upload_ms"] = {}
     for cfg in (2, 3, 4):

@@ -102,11 +102,51 @@ void set_box(float c[3], float h[3], const Box3& b) {
 }
 
 // World AABB of one primitive from its world->primitive transform.
-bool leaf_aabb(const SdfOperationBlock& b, Box3* box) {
-    const float* m = b.bounding_box.trans_inverse.m;
-    double A[3][3], I[3][3];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) A[r][c] = m[4 * c + r];
+// A world -> frame map q = r p + t in double (what a chain of trans_inverse matrices composes to).
+struct Aff {
+    double r[3][3];
+    double t[3];
+};
+Aff aff_of(const float* m) {   // column-major 4x4 with an affine bottom row
+    Aff a;
+    for (int i = 0; i < 3; ++i) {
+        for (int c = 0; c < 3; ++c) a.r[i][c] = m[4 * c + i];
+        a.t[i] = m[12 + i];
+    }
+    return a;
+}
+Aff aff_identity() {
+    Aff a{};
+    for (int i = 0; i < 3; ++i) a.r[i][i] = 1.0;
+    return a;
+}
+Aff aff_then(const Aff& first, const Aff& second) {   // second(first(p))
+    Aff o;
+    for (int i = 0; i < 3; ++i) {
+        for (int c = 0; c < 3; ++c) o.r[i][c] = second.r[i][0] * first.r[0][c] + second.r[i][1] * first.r[1][c] + second.r[i][2] * first.r[2][c];
+        o.t[i] = second.r[i][0] * first.t[0] + second.r[i][1] * first.t[1] + second.r[i][2] * first.t[2] + second.t[i];
+    }
+    return o;
+}
+double aff_lipschitz(const Aff& a) {   // as lipschitz3, for a composed map
+    double worst = 0.0;
+    for (int x = 0; x < 3; ++x) {
+        double row = 0.0;
+        for (int y = 0; y < 3; ++y) {
+            double sum = 0;
+            for (int i = 0; i < 3; ++i) sum += a.r[i][x] * a.r[i][y];
+            row += std::fabs(sum);
+        }
+        worst = std::max(worst, row);
+    }
+    return std::sqrt(worst);
+}
+
+// World AABB of one primitive from its world -> primitive map (its own trans_inverse, or the whole chain of
+// its ancestors' and its own composed).  extra_pad: rounding accumulated over a chain, in world units.
+bool aff_aabb(const Aff& M, const SdfOperationBlock& b, double extra_pad, Box3* box) {
+    const double (*A)[3] = M.r;
+    double I[3][3];
     double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
     double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
     double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
@@ -116,7 +156,7 @@ bool leaf_aabb(const SdfOperationBlock& b, Box3* box) {
     I[0][0] = c00 * r; I[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * r; I[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * r;
     I[1][0] = c01 * r; I[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * r; I[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * r;
     I[2][0] = c02 * r; I[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * r; I[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * r;
-    double t[3] = {m[12], m[13], m[14]};
+    const double* t = M.t;
     double ext[3], cen[3];
     for (int i = 0; i < 3; ++i) {
         cen[i] = -(I[i][0] * t[0] + I[i][1] * t[1] + I[i][2] * t[2]);
@@ -130,12 +170,13 @@ bool leaf_aabb(const SdfOperationBlock& b, Box3* box) {
         }
         // outward padding: the leaf value the kernels compute carries the
         // rounding of a 3x4 mat-vec at |coordinate| magnitude.
-        double pad = 1e-4 * ext[i] + 64.0 * (double)FLT_EPSILON * (std::fabs(cen[i]) + ext[i] + 1.0);
+        double pad = 1e-4 * ext[i] + 64.0 * (double)FLT_EPSILON * (std::fabs(cen[i]) + ext[i] + 1.0) + extra_pad;
         box->lo[i] = cen[i] - ext[i] - pad;
         box->hi[i] = cen[i] + ext[i] + pad;
     }
     return true;
 }
+bool leaf_aabb(const SdfOperationBlock& b, Box3* box) { return aff_aabb(aff_of(b.bounding_box.trans_inverse.m), b, 0.0, box); }
 
 void fill_obb(const SdfBoundingBoxBlock& bb, float fi[12], float sc[3]) {
     for (int r = 0; r < 3; ++r)
@@ -433,7 +474,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     if (dt[0].level != 1) return fail(err, SDFGPU_ERR_BAD_TREE, "root level is %u, expected 1", dt[0].level);
     if (dt[0].len != n - 1) return fail(err, SDFGPU_ERR_BAD_TREE, "root len %u does not span buffer_len %u", dt[0].len, n);
     uint32_t n_prims = 0, n_inner = 0, max_level = 0, max_level_live = 0;
-    bool identity_inner = true, rigid = true, exact_rows = true;
+    bool identity_inner = true, rigid = true, exact_rows = true, inner_rigid = true;
     // A clone node (op 1) evaluates to +inf as the flat query is written: uptree op 1 returns
     // the RIGHT branch distance (faux_shader.rs:90) and a one-slot node only fills the left one
     // (:162,177).  Its whole subtree is therefore "dead": validated, numbered, never resident.
@@ -453,7 +494,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         uint8_t flags;       // HEAD_* below
         float param_max;     // largest |size parameter| (radius; half extents; frame dimensions)
     };
-    enum : uint8_t { HEAD_TI_FINITE = 1, HEAD_TI_IDENTITY = 2, HEAD_P0_BAD = 4, HEAD_VEC_BAD = 8 };
+    enum : uint8_t { HEAD_TI_FINITE = 1, HEAD_TI_IDENTITY = 2, HEAD_P0_BAD = 4, HEAD_VEC_BAD = 8, HEAD_INNER_RIGID = 16 };
     std::vector<Head> head(n);
     parallel_for(n, 8192, [&](uint32_t lo, uint32_t hi) {
         for (uint32_t i = lo; i < hi; ++i) {
@@ -464,6 +505,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
             const float* ti = b.bounding_box.trans_inverse.m;
             h.flags = finite16(ti) ? HEAD_TI_FINITE : 0;
             if (!b.is_primitive && is_identity(ti)) h.flags |= HEAD_TI_IDENTITY;
+            if (!b.is_primitive && bottom_row_exact(ti) && rigid3(ti, RIGID_TOL)) h.flags |= HEAD_INNER_RIGID;   // chain path
             h.param_max = 0.f;
             if (b.is_primitive) {
                 const float p0 = b.op_specific.floats[0];   // sphere: radius; box frame: thickness
@@ -519,6 +561,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 return fail(err, SDFGPU_ERR_UNSUPPORTED_OP, "Unsupported downtree op code: %u (node %u)", b.op_code, i);
             if (b.len == 0) return fail(err, SDFGPU_ERR_BAD_TREE, "operation node %u has no children", i);
             if (!dead && !(b.flags & HEAD_TI_IDENTITY)) identity_inner = false;
+            if (!dead && !(b.flags & HEAD_INNER_RIGID)) inner_rigid = false;
             if (!dead) ++n_inner;
             uint32_t end = i + b.len, k = i + 1, cnt = 0;
             while (k <= end) {
@@ -607,7 +650,61 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     }
 
     out->info.extensions = ext_in_use;
-    if (!identity_inner || !exact_rows || ext_in_use) {
+    std::vector<uint32_t> parent_of(n, REF_NONE);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t k : {c.child0[i], c.child1[i]})
+            if (k != REF_NONE) parent_of[k] = i;
+    // Chain path (round 3): internal nodes that re-base the point, but every map affine and rigid and no extension
+    // in effect: the library's own hierarchy over world boxes of the composed maps prunes, leaf values keep the
+    // reference's one rounded mat-vec per level.  SDFGPU_CHAIN=0 sends such buffers to the exhaustive path again.
+    static const bool chain_env = [] { const char* e = std::getenv("SDFGPU_CHAIN"); return !(e && std::atoi(e) == 0); }();
+    bool chain = !identity_inner && exact_rows && inner_rigid && rigid && !ext_in_use && chain_env &&
+                 (bounds == SDFGPU_BOUNDS_AUTO || bounds == SDFGPU_BOUNDS_BVH);
+    std::vector<uint32_t> chain_len;   // per node: non-identity internal maps from the root down to and including it
+    if (chain) {
+        chain_len.assign(n, 0);
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < n && chain; ++i) {
+            if (c.dead[i] || head[i].is_primitive) continue;
+            const uint32_t up = parent_of[i] == REF_NONE ? 0u : chain_len[parent_of[i]];
+            chain_len[i] = up + ((head[i].flags & HEAD_TI_IDENTITY) ? 0u : 1u);
+            if (chain_len[i] > CHAIN_MAX_LEVELS) chain = false;
+            bool leaf_child = false;
+            for (uint32_t k : {c.child0[i], c.child1[i]})
+                if (k != REF_NONE && head[k].is_primitive && !c.dead[k]) leaf_child = true;
+            if (leaf_child) total += chain_len[i];
+        }
+        if (total > (1ull << 24)) chain = false;   // 1 GiB of chain records: such a buffer stays on the exhaustive path
+    }
+    // chain path: world -> "frame handed to the children" of every live internal node, composed in double, and the
+    // sum of the translations met on the way (the magnitude the intermediate points of the chain can reach)
+    std::vector<Aff> in_aff;
+    std::vector<double> in_tsum;
+    if (chain) {
+        in_aff.resize(n);
+        in_tsum.assign(n, 0.0);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (c.dead[i] || head[i].is_primitive) continue;
+            const uint32_t par = parent_of[i];
+            const Aff up = par == REF_NONE ? aff_identity() : in_aff[par];
+            const float* m = dt[i].bounding_box.trans_inverse.m;
+            in_aff[i] = (head[i].flags & HEAD_TI_IDENTITY) ? up : aff_then(up, aff_of(m));
+            in_tsum[i] = (par == REF_NONE ? 0.0 : in_tsum[par]) + std::fabs((double)m[12]) + std::fabs((double)m[13]) + std::fabs((double)m[14]);
+        }
+        // the pruned walk compares world distances with leaf values: the COMPOSED map of every leaf has to be an
+        // isometry to the same tolerance a single leaf map is held to (tolerances of the levels add up)
+        for (uint32_t i = 0; i < n && chain; ++i) {
+            if (!head[i].is_primitive || c.dead[i] || parent_of[i] == REF_NONE) continue;
+            const Aff M = aff_then(in_aff[parent_of[i]], aff_of(dt[i].bounding_box.trans_inverse.m));
+            for (int x = 0; x < 3 && chain; ++x)
+                for (int y = 0; y < 3; ++y) {
+                    double sum = 0;
+                    for (int r = 0; r < 3; ++r) sum += M.r[r][x] * M.r[r][y];
+                    if (!(std::fabs(sum - (x == y ? 1.0 : 0.0)) <= RIGID_TOL)) { chain = false; break; }
+                }
+        }
+    }
+    if ((!identity_inner || !exact_rows || ext_in_use) && !chain) {
         // General path: no pruning, the literal per-level point chain.
         if (bounds == SDFGPU_BOUNDS_AABB || bounds == SDFGPU_BOUNDS_OBB || bounds == SDFGPU_BOUNDS_BVH)
             return fail(err, SDFGPU_ERR_BAD_TREE,
@@ -619,10 +716,6 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                         max_level_live);
         out->gen.reserve(n);
         std::vector<uint32_t> gen_of(n, REF_NONE);   // node -> index in the resident array
-        std::vector<uint32_t> parent_of(n, REF_NONE);
-        for (uint32_t i = 0; i < n; ++i)
-            for (uint32_t k : {c.child0[i], c.child1[i]})
-                if (k != REF_NONE) parent_of[k] = i;
         for (uint32_t i = 0; i < n; ++i) {
             if (c.dead[i]) continue;   // clone subtrees contribute +inf as written: left out of the walk
             gen_of[i] = (uint32_t)out->gen.size();
@@ -709,6 +802,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 for (int r = 0; r < 3; ++r)
                     for (int col = 0; col < 4; ++col) L.m[4 * r + col] = m[4 * col + r];
                 mt = std::max(mt, std::fabs(m[12]) + std::fabs(m[13]) + std::fabs(m[14]));
+                if (chain && parent_of[i] != REF_NONE) mt = std::max(mt, (float)in_tsum[parent_of[i]] + std::fabs(m[12]) + std::fabs(m[13]) + std::fabs(m[14]));
                 L.kind = dt[i].op_code;
                 if (L.kind == SDF_PRIM_SPHERE) {
                     L.param[0] = dt[i].op_specific.floats[0];
@@ -740,7 +834,15 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
                 const uint32_t i = live_nodes[j];
                 PrimBox& q = prims[j];
                 q.id = c.prim_id[i];
-                if (!leaf_aabb(dt[i], &q.b)) {
+                bool ok;
+                if (chain && parent_of[i] != REF_NONE) {
+                    const uint32_t par = parent_of[i];
+                    const double pad = 8.0 * (double)FLT_EPSILON * (double)(chain_len[par] + 1u) * (in_tsum[par] + 1.0);
+                    ok = aff_aabb(aff_then(in_aff[par], aff_of(dt[i].bounding_box.trans_inverse.m)), dt[i], pad, &q.b);
+                } else {
+                    ok = leaf_aabb(dt[i], &q.b);
+                }
+                if (!ok) {
                     uint32_t seen = singular.load();
                     while (i < seen && !singular.compare_exchange_weak(seen, i)) {
                     }
@@ -763,6 +865,40 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         if (depth > budget) return fail(err, SDFGPU_ERR_TOO_DEEP, "built hierarchy is %u levels deep (budget %u)", depth, budget);
     } else {
         out->root_ref = emit(c, 0, &root, &depth);
+    }
+    if (chain) {
+        // the composed maps decide how fast a leaf value can change, and the chain records themselves
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!dt[i].is_primitive || c.dead[i] || parent_of[i] == REF_NONE) continue;
+            lip = std::max(lip, aff_lipschitz(aff_then(in_aff[parent_of[i]], aff_of(dt[i].bounding_box.trans_inverse.m))));
+        }
+        out->leaf_chain.assign((size_t)n_prims * 2u, 0u);
+        std::vector<uint32_t> path;
+        for (uint32_t a = 0; a < n; ++a) {
+            if (c.dead[a] || head[a].is_primitive) continue;
+            bool leaf_child = false;
+            for (uint32_t k : {c.child0[a], c.child1[a]})
+                if (k != REF_NONE && head[k].is_primitive && !c.dead[k]) leaf_child = true;
+            if (!leaf_child) continue;
+            path.clear();
+            for (uint32_t k = a; k != REF_NONE; k = parent_of[k])
+                if (!(head[k].flags & HEAD_TI_IDENTITY)) path.push_back(k);
+            const uint32_t off = (uint32_t)out->chain_mats.size();
+            for (size_t j = path.size(); j-- > 0;) {   // root first
+                GpuChainMat g;
+                std::memset(&g, 0, sizeof g);
+                const float* m = dt[path[j]].bounding_box.trans_inverse.m;
+                for (int r = 0; r < 3; ++r)
+                    for (int col = 0; col < 4; ++col) g.m[4 * r + col] = m[4 * col + r];
+                out->chain_mats.push_back(g);
+            }
+            out->chain_max = std::max(out->chain_max, (uint32_t)path.size());
+            for (uint32_t k : {c.child0[a], c.child1[a]})
+                if (k != REF_NONE && head[k].is_primitive && !c.dead[k]) {
+                    out->leaf_chain[2u * c.prim_id[k]] = off;
+                    out->leaf_chain[2u * c.prim_id[k] + 1u] = (uint32_t)path.size();
+                }
+        }
     }
     out->stack_depth = std::max(1u, depth);
     out->margin_T = margin_T;
@@ -792,7 +928,8 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     info.identity_inner = identity_inner ? 1 : 0;
     info.rigid_leaves = rigid ? 1 : 0;
     info.device_bytes = out->leaves.size() * sizeof(GpuLeaf) + out->inner.size() * sizeof(GpuInner) +
-                        out->inner_obb.size() * sizeof(GpuInnerObb);
+                        out->inner_obb.size() * sizeof(GpuInnerObb) + out->chain_mats.size() * sizeof(GpuChainMat) +
+                        out->leaf_chain.size() * sizeof(uint32_t);
     // scene box (query reordering uses it in every mode; exact only for rigid leaves)
     {
         Box3 sb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};

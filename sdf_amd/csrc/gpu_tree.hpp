@@ -79,7 +79,23 @@ struct alignas(64) GpuGenNode {
 };
 static_assert(sizeof(GpuGenNode) == 192, "GpuGenNode is three 64-byte lines");
 
+// Chain path: a buffer whose internal nodes re-base the point (what the crate's own SdfBoundingBox::merge
+// emits, obb.rs:183-185) is pruned over world boxes of the COMPOSED maps, but a leaf value is still the
+// reference's sequence of one rounded mat-vec per level (faux_shader.rs:165,175).  One record per level: rows of
+// that node's trans_inverse (affine: bottom row exactly 0 0 0 1, so the 3x4 form is bit-identical).
+struct alignas(64) GpuChainMat {
+    float m[12];
+    uint32_t pad[4];
+};
+static_assert(sizeof(GpuChainMat) == 64, "GpuChainMat is one 64-byte line");
+constexpr uint32_t CHAIN_MAX_LEVELS = 64;
+
 struct CompactTree {
+    // chain path (empty otherwise): per primitive {first record, count} into chain_mats -- the non-identity
+    // trans_inverse of its ancestors, root first (its own is in its GpuLeaf)
+    std::vector<GpuChainMat> chain_mats;
+    std::vector<uint32_t> leaf_chain;   // 2 per primitive
+    uint32_t chain_max = 0;
     std::vector<GpuGenNode> gen;        // general path (empty otherwise)
     bool gen_eval = false;              // general path must run the post-order combine (a smooth union is in effect)
     std::vector<GpuLeaf> leaves;

@@ -185,13 +185,18 @@ struct TreeView {
     // arguments its 13 values stayed live in SGPRs across the whole march loop and cost the kernel its eighth
     // wavefront per SIMD (106 SGPRs).  Null: no grid.
     const void* __restrict__ gblock;
+    // chain path (kernels.hpp DeviceTree::chain; the CHAIN instantiations only): per primitive {first, count}, then the
+    // records; mg_scale = 1 + longest chain (the rounding of a leaf value grows with the levels it passes through)
+    const void* __restrict__ chain;
+    float mg_scale;
 };
 
 // Absolute slack covering the rounding of a leaf value at point p (DESIGN.md "pruning").
-template <int MODE>
+template <int MODE, bool CHAIN = false>
 __device__ __forceinline__ float prune_margin(const TreeView& T, float px, float py, float pz) {
     // T.lip scales it for non-rigid leaves (NONE mode only): the rounding of M p grows with |M|
-    const float mg_k = ((MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f) * T.lip;
+    float mg_k = ((MODE == SDFGPU_BOUNDS_OBB) ? 1.2e-5f : 3.0e-6f) * T.lip;
+    if constexpr (CHAIN) mg_k *= T.mg_scale;   // one rounded mat-vec per level of the chain (margin_T holds the translations' sum)
     return mg_k * (__builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + T.margin_T);
 }
 
@@ -290,6 +295,21 @@ __device__ __forceinline__ uint32_t load_u32_scalar(const void* __restrict__ bas
     return r;
 }
 
+// 64 bytes at base + byte offset into the walk's record tuple (chain records).
+__device__ __forceinline__ f32x16 load_rec64_s48_at(const void* __restrict__ base, uint32_t byte_off) {
+    f32x16 r;
+    const uint32_t off = __builtin_amdgcn_readfirstlane(byte_off);
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&{s[48:63]}"(r) : "s"(base), "s"(off) : "memory");
+    return r;
+}
+__device__ __forceinline__ void load_u32x2_scalar(const void* __restrict__ base, uint32_t byte_off, uint32_t& a, uint32_t& b) {
+    unsigned long long r;
+    const uint32_t off = __builtin_amdgcn_readfirstlane(byte_off);
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(off) : "memory");
+    a = (uint32_t)r;
+    b = (uint32_t)(r >> 32);
+}
+
 // Bits of one float element of such a record as an integer.  A plain bit cast of
 // an extracted element is miscompiled by this toolchain (it reads element 0 of
 // the SGPR tuple), so the reinterpretation is one explicit scalar move.
@@ -304,6 +324,35 @@ __device__ __forceinline__ float leaf_eval_rec(const f32x16& r, float px, float 
     const float ly = ((r[4] * px + r[5] * py) + r[6] * pz) + r[7];
     const float lz = ((r[8] * px + r[9] * py) + r[10] * pz) + r[11];
     return prim_value(rec_bits(r[15]), r[12], r[13], r[14], lx, ly, lz);
+}
+
+// Value of primitive `id` at a world point.  Plain trees: the record the walk fetched.  CHAIN: the reference's point
+// chain first -- one rounded 3x4 mat-vec per re-basing ancestor, root first (faux_shader.rs:165,175: never
+// pre-multiplied) -- then the primitive's own record.  Chain records arrive by scalar loads into the walk's record
+// tuple (which the leaf record is then fetched into again: a scalar-cache hit).
+struct TreeView;
+template <bool CHAIN>
+__device__ __forceinline__ float leaf_value(const TreeView& T, uint32_t id, const f32x16& L, float px, float py, float pz);
+
+template <bool CHAIN>
+__device__ __forceinline__ float leaf_value(const TreeView& T, uint32_t id, const f32x16& L, float px, float py, float pz) {
+    if constexpr (!CHAIN) {
+        return leaf_eval_rec(L, px, py, pz);
+    } else {
+        uint32_t first, cnt;
+        load_u32x2_scalar(T.chain, id << 3, first, cnt);
+        const uint32_t mats = (T.n_leaf * 8u + 63u) & ~63u;
+        float x = px, y = py, z = pz;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const f32x16 M = load_rec64_s48_at(T.chain, mats + ((first + j) << 6));
+            const float nx = ((M[0] * x + M[1] * y) + M[2] * z) + M[3];
+            const float ny = ((M[4] * x + M[5] * y) + M[6] * z) + M[7];
+            const float nz = ((M[8] * x + M[9] * y) + M[10] * z) + M[11];
+            x = nx; y = ny; z = nz;
+        }
+        const f32x16 R = load_rec64_s48(T.leaf, id);
+        return leaf_eval_rec(R, x, y, z);
+    }
 }
 
 // Wave-uniform branch-and-prune walk.  On return the accumulator holds the
@@ -618,13 +667,13 @@ __device__ __forceinline__ void walk_advance(uint32_t& cur, uint32_t& sp, int& r
 #undef SDFGPU_WALK_CLOBBER
 }
 
-template <int MODE, bool DBG, bool PF, bool FAR, class Acc>
+template <int MODE, bool DBG, bool PF, bool FAR, bool CHAIN, class Acc>
 __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, float py, float pz,
                                                 unsigned long long drive, float ext, Acc& acc,
                                                 float* __restrict__ stk, uint32_t lane, WaveCounters& wc) {
     uint32_t cur = __builtin_amdgcn_readfirstlane(T.root);
     if (cur == REF_NONE) return;
-    const float mg = prune_margin<MODE>(T, px, py, pz);
+    const float mg = prune_margin<MODE, CHAIN>(T, px, py, pz);
     uint32_t sp = 0;
     int refs = 0;   // lane k holds the reference of stack entry k
     float lb = __builtin_inff();
@@ -641,7 +690,7 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (cur == REF_NONE) break;
         const uint32_t id = cur & REF_INDEX;
-        acc.offer(leaf_eval_rec(L, px, py, pz), id);
+        acc.offer(leaf_value<CHAIN>(T, id, L, px, py, pz), id);
         thr = prune_threshold<MODE>(acc.radius(), mg, ext, T.bscale);
         cur = REF_POP;
     }
@@ -659,15 +708,16 @@ __device__ __forceinline__ void nn_traverse_asm(const TreeView& T, float px, flo
 // eye and far plane are both well inside it: launch_render_m decides on the host), so that kernel carries
 // neither the per-walk test nor the far copy -- which in the march's loop cost 1.2 % of the frame, and four
 // more SGPRs for a flag instead cost it its eighth wavefront per SIMD (9 %).
-template <int MODE, int COUNT, bool FARCHK = true, class Acc>
+template <int MODE, int COUNT, bool FARCHK = true, bool CHAIN = false, class Acc>
 __device__ __forceinline__ void nn_traverse(const TreeView& T, float px, float py, float pz, unsigned long long drive,
                                             float ext, Acc& acc, float* __restrict__ stk, uint32_t lane,
                                             WaveCounters& wc) {
+    static_assert(!CHAIN || (MODE != SDFGPU_BOUNDS_OBB && COUNT == 0), "the chain path runs the assembly walk over the library's own hierarchy, uncounted");
     if constexpr (MODE == SDFGPU_BOUNDS_OBB || COUNT == 1) nn_traverse_cxx<MODE, COUNT != 0>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
     else if (FARCHK && (__builtin_amdgcn_ballot_w64(far_point(px, py, pz, T.inv_bscale)) & drive) != 0ull)
-        nn_traverse_asm<MODE, COUNT == 2, false, true>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else if (__builtin_amdgcn_readfirstlane(T.prefetch)) nn_traverse_asm<MODE, COUNT == 2, true, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
-    else nn_traverse_asm<MODE, COUNT == 2, false, false>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+        nn_traverse_asm<MODE, COUNT == 2, false, true, CHAIN>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else if (__builtin_amdgcn_readfirstlane(T.prefetch)) nn_traverse_asm<MODE, COUNT == 2, true, false, CHAIN>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
+    else nn_traverse_asm<MODE, COUNT == 2, false, false, CHAIN>(T, px, py, pz, drive, ext, acc, stk, lane, wc);
 }
 
 __device__ __forceinline__ void flush_counters(const WaveCounters& wc, uint32_t lane, uint32_t steps, uint32_t rays,
@@ -743,7 +793,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
 // the primitive index.  One point per lane.  `order` (optional) is a
 // permutation that makes consecutive lanes spatially close (Morton order);
 // results are written at the original index.
-template <int MODE, int COUNT>
+template <int MODE, int COUNT, bool CHAIN = false>
 __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* __restrict__ pts,
                                                       const uint32_t* __restrict__ order, uint32_t n,
                                                       float* __restrict__ out_dist, uint32_t* __restrict__ out_prim,
@@ -763,7 +813,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     WaveCounters wc;
     AccNearest acc{best, bid};
     const bool in_dom = in_domain3(p.x, p.y, p.z);
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
+    nn_traverse<MODE, COUNT, true, CHAIN>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
     best = in_dom ? acc.best : __builtin_nanf("");
     bid = in_dom ? acc.bid : SDF_NO_PRIM;
     if (alive) {
@@ -832,7 +882,7 @@ struct AccK {
     }
 };
 
-template <int MODE, int K, bool COUNT>
+template <int MODE, int K, bool COUNT, bool CHAIN = false>
 __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __restrict__ pts,
                                                   const uint32_t* __restrict__ order, uint32_t n, uint32_t k,
                                                   float* __restrict__ out_dist, uint32_t* __restrict__ out_prim,
@@ -851,7 +901,7 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     acc.init();
     WaveCounters wc;
     const bool in_dom = in_domain3(p.x, p.y, p.z);
-    nn_traverse<MODE, COUNT>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
+    nn_traverse<MODE, COUNT, true, CHAIN>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
     if (!in_dom) acc.init_nan();
     if (alive) {
         // whole rows as 16-byte stores when the row is exactly K wide (rows are K * 4 bytes apart, so they
@@ -921,14 +971,14 @@ struct PassArgs {
 // (45 internal nodes and 3 primitives per wavefront on the bench frame, 4 % of a frame's visits) is made once,
 // by one wavefront whose 64 lanes all hold that point -- identical needs, so the nodes visited, the bounds kept
 // and the result are what each tile's own first walk would have produced.
-template <int MODE>
+template <int MODE, bool CHAIN = false>
 __global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, float ey, float ez, float4* __restrict__ out) {
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63u;
     AccTracked acc{__builtin_inff(), SDF_NO_PRIM, __builtin_inff(), __builtin_inff()};
     WaveCounters wc;
     if (!march_domain(ex, ey, ez, 0.f)) return;   // no ray of such a frame marches (march_domain): nobody reads *out
-    nn_traverse<MODE, 0>(T, ex, ey, ez, ~0ull, T.skip_ext, acc, smem, lane, wc);
+    nn_traverse<MODE, 0, true, CHAIN>(T, ex, ey, ez, ~0ull, T.skip_ext, acc, smem, lane, wc);
     if (lane == 0) *out = make_float4(acc.best, __builtin_bit_cast(float, acc.bid), acc.lb_key, acc.second);
 }
 
@@ -942,7 +992,7 @@ __global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, floa
 // against ~30 box tests + ~4 evaluations for a walk on the bench frame.  What the lane keeps for certifying its
 // next steps: `second` over everything evaluated, and the cell's lower bound on everything not in its list.
 // Returns false (and touches nothing) when no marching lane has a list: the caller walks.
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool CHAIN>
 __device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py, float pz, float mg, bool active, uint32_t lane,
                                           float& best, uint32_t& bid, float& budget, bool& adv, WaveCounters& wc) {
     if constexpr (MODE == SDFGPU_BOUNDS_OBB) return false;
@@ -988,7 +1038,7 @@ __device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py,
             done = (lane == n_done) ? id : done;
             n_done += 1;
             const f32x16 L = load_rec64_s48(T.leaf, id);
-            acc.offer(leaf_eval_rec(L, px, py, pz), id);
+            acc.offer(leaf_value<CHAIN>(T, id, L, px, py, pz), id);
             if constexpr (COUNT) {
                 wc.wave_list_evals += 1;
                 const uint32_t want = (has_list && bi == sb && ((gc.mask >> b) & 1u)) ? 1u : 0u;
@@ -1012,7 +1062,7 @@ __device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py,
     return true;
 }
 
-template <int MODE, bool COUNT, bool FIRST, bool FAR>
+template <int MODE, bool COUNT, bool FIRST, bool FAR, bool CHAIN = false>
 __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_camera cam, uint32_t width, uint32_t height,
                                                           sdfgpu_march_params mp, uint32_t tile_first,
                                                           uint32_t tile_stride, uint32_t tile_count, uint32_t row_major,
@@ -1110,10 +1160,11 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     uint32_t state = alive ? 0u : 2u;
     // record of `last`, kept in registers between walks: certified steps touch no memory
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
-    if (alive && last != SDF_NO_PRIM) {
+    if (!CHAIN && alive && last != SDF_NO_PRIM) {
         const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
         c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
     }
+    const f32x16 no_rec{};   // CHAIN: leaf_value fetches its records itself
     // FIRST pass with the eye's walk at hand: taken instead of this wavefront's own first walk when every
     // marching lane really stands at the eye (a degenerate ray direction would put a lane elsewhere)
     bool eye_step = false;
@@ -1129,12 +1180,30 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         px = ox + dx * t;
         py = oy + dy * t;
         pz = oz + dz * t;
-        const float mg = prune_margin<MODE>(T, px, py, pz);
+        const float mg = prune_margin<MODE, CHAIN>(T, px, py, pz);
         const bool seeded = last != SDF_NO_PRIM;
-        const float lx = ((c0.x * px + c0.y * py) + c0.z * pz) + c0.w;
-        const float ly = ((c1.x * px + c1.y * py) + c1.z * pz) + c1.w;
-        const float lz = ((c2.x * px + c2.y * py) + c2.z * pz) + c2.w;
-        const float seed = prim_value_lane(__builtin_bit_cast(uint32_t, c3.w), c3.x, c3.y, c3.z, lx, ly, lz);
+        float seed;
+        if constexpr (CHAIN) {
+            // A seed's value goes through its whole chain, whose records cannot be kept per lane: the distinct seeds of
+            // the marching lanes (one to three in a tile's wavefront) are evaluated one after the other, wave-uniformly
+            // like a visited leaf; every lane keeps the value of its own.
+            seed = __builtin_inff();
+            uint32_t lw = (active & seeded) ? last : SDF_NO_PRIM;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(lw != SDF_NO_PRIM);
+            while (todo != 0ull) {
+                const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)__builtin_ctzll(todo));
+                const float v = leaf_value<true>(T, sid, no_rec, px, py, pz);
+                const bool same = lw == sid;
+                seed = same ? v : seed;
+                lw = same ? SDF_NO_PRIM : lw;
+                todo = __builtin_amdgcn_ballot_w64(lw != SDF_NO_PRIM);
+            }
+        } else {
+            const float lx = ((c0.x * px + c0.y * py) + c0.z * pz) + c0.w;
+            const float ly = ((c1.x * px + c1.y * py) + c1.z * pz) + c1.w;
+            const float lz = ((c2.x * px + c2.y * py) + c2.z * pz) + c2.w;
+            seed = prim_value_lane(__builtin_bit_cast(uint32_t, c3.w), c3.x, c3.y, c3.z, lx, ly, lz);
+        }
         float best = seeded ? seed : __builtin_inff();
         uint32_t bid = last;
         const bool c_bound = (best + 2.0f * mg) < budget;
@@ -1145,7 +1214,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         if (cheap) {
             adv = certified;   // the others hold their position
             n_cheap += 1;
-        } else if (list_pass<MODE, COUNT>(T, px, py, pz, mg, active, lane, best, bid, budget, adv, wc)) {
+        } else if (list_pass<MODE, COUNT, CHAIN>(T, px, py, pz, mg, active, lane, best, bid, budget, adv, wc)) {
             // no marching lane can certify, but some stand in a grid cell with a candidate list: those lanes took
             // their step on the list (list_pass); the others (outside the grid, cells without a list) hold their
             // position until nobody can step otherwise, then the wavefront walks for them
@@ -1169,7 +1238,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
                 acc.second = e.w;
             } else {
                 if constexpr (COUNT) wc.wave_walks += 1;
-                nn_traverse<MODE, COUNT, FAR>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
+                nn_traverse<MODE, COUNT, FAR, CHAIN>(T, px, py, pz, dmask, ext, acc, stk, lane, wc);
             }
             best = acc.best;
             bid = acc.bid;
@@ -1199,7 +1268,7 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         s += adv ? 1u : 0u;
         state = hit_now ? 1u : ((go & !(tn <= t_hi)) ? 2u : state);
         eye_step = false;   // only the very first iteration of a ray's march can stand at the eye
-        if (!cheap) {   // the walk may have changed `last`: fetch its record once
+        if (!CHAIN && !cheap) {   // the walk may have changed `last`: fetch its record once
             if ((state == 0u) & (s < pa.step_end) & (last != SDF_NO_PRIM)) {   // (an empty tree has no nearest primitive)
                 const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
                 c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
@@ -1219,14 +1288,33 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         }
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (hit) {
-        const GpuLeaf* L = T.leaf + hit_prim;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+    if constexpr (CHAIN) {   // the taps of every distinct hit primitive, wave-uniformly (as the seeds above)
         const float h = mp.normal_h;
-        // k.xyy, k.yyx, k.yxy, k.xxx with k = (1,-1)
-        const float f0 = leaf_eval(L, px + h, py - h, pz - h);
-        const float f1 = leaf_eval(L, px - h, py - h, pz + h);
-        const float f2 = leaf_eval(L, px - h, py + h, pz - h);
-        const float f3 = leaf_eval(L, px + h, py + h, pz + h);
+        uint32_t hw = hit ? hit_prim : SDF_NO_PRIM;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(hw != SDF_NO_PRIM);
+        while (todo != 0ull) {
+            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)hw, (int)__builtin_ctzll(todo));
+            const float v0 = leaf_value<true>(T, sid, no_rec, px + h, py - h, pz - h);
+            const float v1 = leaf_value<true>(T, sid, no_rec, px - h, py - h, pz + h);
+            const float v2 = leaf_value<true>(T, sid, no_rec, px - h, py + h, pz - h);
+            const float v3 = leaf_value<true>(T, sid, no_rec, px + h, py + h, pz + h);
+            const bool same = hw == sid;
+            f0 = same ? v0 : f0; f1 = same ? v1 : f1; f2 = same ? v2 : f2; f3 = same ? v3 : f3;
+            hw = same ? SDF_NO_PRIM : hw;
+            todo = __builtin_amdgcn_ballot_w64(hw != SDF_NO_PRIM);
+        }
+    }
+    if (hit) {
+        if constexpr (!CHAIN) {
+            const GpuLeaf* L = T.leaf + hit_prim;
+            const float h = mp.normal_h;
+            // k.xyy, k.yyx, k.yxy, k.xxx with k = (1,-1)
+            f0 = leaf_eval(L, px + h, py - h, pz - h);
+            f1 = leaf_eval(L, px - h, py - h, pz + h);
+            f2 = leaf_eval(L, px - h, py + h, pz - h);
+            f3 = leaf_eval(L, px + h, py + h, pz + h);
+        }
         const float sx = ((f0 - f1) - f2) + f3;
         const float sy = ((-f0 - f1) + f2) + f3;
         const float sz = ((-f0 + f1) - f2) + f3;
@@ -1694,6 +1782,8 @@ static TreeView make_view(const DeviceTree& d, size_t prefetch_beyond = 4u << 20
     v.bscale = d.box_scale;
     v.inv_bscale = 1.0f / d.box_scale;
     v.gblock = d.grid.cells ? d.grid.block : nullptr;
+    v.chain = d.chain;
+    v.mg_scale = 1.0f + (float)d.chain_max;
     static const int forced = [] { const char* e = std::getenv("SDFGPU_PREFETCH"); return e ? std::atoi(e) : -1; }();
     v.xcd = 0;   // set by query_grid for the query kernels
     v.prefetch = forced >= 0 ? (uint32_t)(forced != 0) : (uint32_t)((size_t)d.n_leaf * (sizeof(GpuLeaf) + sizeof(GpuInner)) > prefetch_beyond);
@@ -1719,7 +1809,10 @@ static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const 
     const uint32_t wpg = wg_waves();
     dim3 grid(query_grid((n + 64u * wpg - 1u) / (64u * wpg), &v)), block(64u * wpg);
     size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
-    if (d.bounds == SDFGPU_BOUNDS_OBB)
+    if (d.chain) {
+        if constexpr (COUNT == 0) nearest_kernel<SDFGPU_BOUNDS_AABB, 0, true><<<grid, block, lds, s>>>(v, (const float4*)pts, order, n, out_dist, out_prim, st);
+        else return hipErrorNotSupported;   // no counting instantiation of the chain path
+    } else if (d.bounds == SDFGPU_BOUNDS_OBB)
         nearest_kernel<SDFGPU_BOUNDS_OBB, COUNT><<<grid, block, lds, s>>>(v, (const float4*)pts, order, n, out_dist, out_prim, st);
     else
         nearest_kernel<SDFGPU_BOUNDS_AABB, COUNT><<<grid, block, lds, s>>>(v, (const float4*)pts, order, n, out_dist, out_prim, st);
@@ -1756,7 +1849,7 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t*
 }
 
 
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool CHAIN = false>
 static hipError_t launch_knn_m(const DeviceTree& d, const float* pts, const uint32_t* order, uint32_t n, uint32_t k,
                                float* out_dist, uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s) {
     TreeView v = make_view(d);
@@ -1764,10 +1857,10 @@ static hipError_t launch_knn_m(const DeviceTree& d, const float* pts, const uint
     dim3 grid(query_grid((n + 64u * wpg - 1u) / (64u * wpg), &v)), block(64u * wpg);
     size_t lds = (size_t)wpg * d.stack_depth * 64 * sizeof(float);
     const float4* p4 = (const float4*)pts;
-    if (k <= 2) knn_kernel<MODE, 2, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
-    else if (k <= 4) knn_kernel<MODE, 4, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
-    else if (k <= 8) knn_kernel<MODE, 8, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
-    else knn_kernel<MODE, 16, COUNT><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    if (k <= 2) knn_kernel<MODE, 2, COUNT, CHAIN><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    else if (k <= 4) knn_kernel<MODE, 4, COUNT, CHAIN><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    else if (k <= 8) knn_kernel<MODE, 8, COUNT, CHAIN><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
+    else knn_kernel<MODE, 16, COUNT, CHAIN><<<grid, block, lds, s>>>(v, p4, order, n, k, out_dist, out_prim, st);
     return hipGetLastError();
 }
 
@@ -1784,6 +1877,10 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
         else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
         return hipGetLastError();
     }
+    if (d.chain) {
+        if (st) return hipErrorNotSupported;   // no counting instantiation of the chain path
+        return launch_knn_m<SDFGPU_BOUNDS_AABB, false, true>(d, pts, order, n, k, out_dist, out_prim, nullptr, s);
+    }
     const bool obb = d.bounds == SDFGPU_BOUNDS_OBB;
     if (st) return obb ? launch_knn_m<SDFGPU_BOUNDS_OBB, true>(d, pts, order, n, k, out_dist, out_prim, st, s)
                        : launch_knn_m<SDFGPU_BOUNDS_AABB, true>(d, pts, order, n, k, out_dist, out_prim, st, s);
@@ -1791,7 +1888,7 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
                : launch_knn_m<SDFGPU_BOUNDS_AABB, false>(d, pts, order, n, k, out_dist, out_prim, nullptr, s);
 }
 
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool CHAIN = false>
 static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t w, uint32_t h,
                                   const sdfgpu_march_params& mp, uint32_t tile_first, uint32_t tile_stride,
                                   uint32_t tile_count, bool row_major, const RenderScratch& rs, const uint32_t* bounds,
@@ -1822,14 +1919,14 @@ static hipError_t launch_render_m(const DeviceTree& d, const sdfgpu_camera& cam,
         pa.tile_cost = (n_bounds == 2 && !COUNT) ? rs.tile_cost : nullptr;
         pa.eye = nullptr;
         if (k == 0 && rs.eye && mp.t_min == 0.0f) {
-            eye_walk_kernel<MODE><<<dim3(1), dim3(64), (size_t)d.stack_depth * 64 * sizeof(float), s>>>(v, cam.eye[0], cam.eye[1], cam.eye[2],
+            eye_walk_kernel<MODE, CHAIN><<<dim3(1), dim3(64), (size_t)d.stack_depth * 64 * sizeof(float), s>>>(v, cam.eye[0], cam.eye[1], cam.eye[2],
                                                                                                          (float4*)rs.eye);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             pa.eye = (const float4*)rs.eye;
         }
 #define SDFGPU_PASS(FIRST, FAR)                                                                                               \
-    render_pass_kernel<MODE, COUNT, FIRST, FAR><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count, \
+    render_pass_kernel<MODE, COUNT, FIRST, FAR, CHAIN><<<grid, block, lds, s>>>(v, cam, w, h, mp, tile_first, tile_stride, tile_count, \
                                                                         row_major ? 1u : 0u, pa, hit, depth, normal, prim, st)
         if (k == 0) { if (far) SDFGPU_PASS(true, true); else SDFGPU_PASS(true, false); }
         else { if (far) SDFGPU_PASS(false, true); else SDFGPU_PASS(false, false); }
@@ -1867,6 +1964,11 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
 #define SDFGPU_RENDER(MODE, COUNT) \
     launch_render_m<MODE, COUNT>(d, cam, w, h, mp, tile_first, tile_stride, tile_count, row_major, rs, pass_bounds, n_bounds, \
                                  hit, depth, normal, prim, st, s)
+    if (d.chain) {
+        if (st) return hipErrorNotSupported;   // no counting instantiation of the chain path
+        return launch_render_m<SDFGPU_BOUNDS_AABB, false, true>(d, cam, w, h, mp, tile_first, tile_stride, tile_count, row_major, rs,
+                                                                 pass_bounds, n_bounds, hit, depth, normal, prim, nullptr, s);
+    }
     if (st) return obb ? SDFGPU_RENDER(SDFGPU_BOUNDS_OBB, true) : SDFGPU_RENDER(SDFGPU_BOUNDS_AABB, true);
     return obb ? SDFGPU_RENDER(SDFGPU_BOUNDS_OBB, false) : SDFGPU_RENDER(SDFGPU_BOUNDS_AABB, false);
 #undef SDFGPU_RENDER

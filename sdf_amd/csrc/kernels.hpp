@@ -49,6 +49,10 @@ struct DeviceTree {
     GpuLeaf* leaf = nullptr;
     GpuInner* inner = nullptr;
     GpuInnerObb* inner_obb = nullptr;
+    // chain path (gpu_tree.hpp GpuChainMat; null otherwise): ONE allocation, [n_leaf x {first, count}] padded to 64
+    // bytes, then the chain records
+    void* chain = nullptr;
+    uint32_t chain_max = 0;             // longest chain (scales the rounding margin)
     GpuGenNode* gen = nullptr;          // general path: all nodes, pre-order
     uint32_t n_gen = 0;
     bool gen_eval = false;              // general path runs the post-order combine (smooth union in effect)

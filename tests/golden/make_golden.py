@@ -76,7 +76,7 @@ def clone_scene():
 
 # bounds modes a fixture can be uploaded with (a buffer with re-basing internal nodes takes AUTO / NONE only)
 ALL_BOUNDS = [1, 2, 3, 4]
-BOUNDS_OK = {"pca_inner_12": [0, 3]}
+BOUNDS_OK = {"pca_inner_12": [0, 3, 4]}
 
 SCENES = {
     "pca_inner_12": pca_inner_scene,

@@ -89,13 +89,24 @@ def test_three_children_rejected():
     assert rc == _ffi.ERR_BAD_TREE and "two children" in msg
 
 
-def test_non_identity_inner_transform_takes_the_general_path():
-    # SURVEY C-3: the crate's literal merged boxes re-base the point; such buffers are
-    # walked exhaustively with the per-level point chain (no pruning is valid for them)
+def test_non_identity_inner_transform_takes_the_chain_or_the_general_path():
+    # SURVEY C-3: the crate's literal merged boxes re-base the point.  Rigid, affine re-basing (what obb.rs:183-185
+    # writes) is pruned over the composed maps' world boxes with the per-level chain kept for the leaf values
+    # (chain path, round 3); asked for without pruning, the buffer is walked exhaustively (general path).
     buf = S.random_scene(9, 3, opts={"pca_trans_inverse": True}).expanded().make_buffer()
     rc, info, msg = S.compact_host(buf)
+    assert rc == 0 and info.bounds == S.BOUNDS_BVH and info.identity_inner == 0, msg
+    n_prims = int(buf.downtree_buffer["is_primitive"].sum())
+    assert info.device_bytes > 64 * (2 * n_prims - 1) + 8 * n_prims    # leaves + hierarchy + per-primitive chain index + chain records
+    rc, info, msg = S.compact_host(buf, bounds=S.BOUNDS_NONE)
     assert rc == 0 and info.bounds == S.BOUNDS_NONE and info.identity_inner == 0, msg
     assert info.device_bytes == 192 * buf.buffer_len    # one three-line GpuGenNode per node
+    # a re-basing node that is not an isometry cannot be pruned over world boxes: exhaustive
+    dt = buf.downtree_buffer.copy()
+    inner = int(np.flatnonzero(dt["is_primitive"] == 0)[1])
+    dt["bounding_box"]["trans_inverse"][inner][0] *= np.float32(1.5)
+    rc, info, msg = S.compact_host(S.SdfTreeBuffer(dt, buf.uptree_buffer))
+    assert rc == 0 and info.bounds == S.BOUNDS_NONE, msg
     for b in (S.BOUNDS_AABB, S.BOUNDS_OBB):
         rc, _, msg = S.compact_host(buf, bounds=b)
         assert rc == _ffi.ERR_BAD_TREE and "identity" in msg
@@ -117,8 +128,10 @@ def test_general_path_depth_limit():
     uchain = np.zeros(40, _ffi.UT_DTYPE)
     uchain["level"] = np.arange(40, 0, -1)
     big = S.SdfTreeBuffer(np.concatenate([chain, dt]), np.concatenate([ut, uchain]))
-    rc, _, msg = S.compact_host(big)
+    rc, _, msg = S.compact_host(big, bounds=S.BOUNDS_NONE)
     assert rc == _ffi.ERR_TOO_DEEP and "general path" in msg
+    rc, info, msg = S.compact_host(big)       # the chain path holds 64 re-basing levels and builds its own hierarchy
+    assert rc == 0 and info.bounds == S.BOUNDS_BVH, msg
 
 
 def test_non_rigid_leaf_falls_back_to_no_pruning():

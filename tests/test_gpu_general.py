@@ -20,11 +20,15 @@ def pca_scene(n, seed):
 @pytest.mark.parametrize("n", [2, 3, 9, 64, 300])
 def test_general_nearest_and_knn(gpu, n):
     buf = pca_scene(n, 0x6E00 + n)
-    info = gpu.upload_tree(buf)
-    assert info.identity_inner == 0 and info.bounds == S.BOUNDS_NONE
     pts = make_points(2000, S.default_extent(n), n)
-    d, i = gpu.nearest(pts)
     d0, i0 = O.nearest(buf, pts, O.MODE_EXHAUSTIVE, threads=8)
+    info = gpu.upload_tree(buf, bounds=S.BOUNDS_NONE)      # the exhaustive general path
+    assert info.identity_inner == 0 and info.bounds == S.BOUNDS_NONE
+    d, i = gpu.nearest(pts)
+    assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+    info = gpu.upload_tree(buf)                             # AUTO: the pruned chain path (round 3)
+    assert info.identity_inner == 0 and info.bounds == S.BOUNDS_BVH
+    d, i = gpu.nearest(pts)
     assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
     # sdfgpu.h promises "the value the reference returns": on these buffers the as-written walk, whose
     # union prune (faux_shader.rs:117-126) tests boxes in a frame the re-based point has left, must
@@ -74,13 +78,45 @@ def test_general_render(gpu):
     L = S.default_extent(n)
     cam = S.camera_look_at((0, 0, -3.5 * L), (0, 0, 0), (0, 1, 0), math.pi / 3, w, h)
     mp = S.march_params(max_steps=96, eps_hit=1e-3, t_min=0.0, t_max=10 * L, normal_h=1e-3)
-    gpu.upload_tree(buf)
-    img = gpu.render(cam, w, h, mp)
     ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
     assert ref["hit"].sum() > 0
-    assert np.array_equal(img["hit"], ref["hit"]) and np.array_equal(img["prim"], ref["prim"])
-    assert np.array_equal(bits(img["depth"]), bits(ref["depth"]))
-    assert np.array_equal(bits(img["normal"]), bits(ref["normal"]))
+    for bounds in (S.BOUNDS_AUTO, S.BOUNDS_NONE):           # the pruned chain path, the exhaustive general path
+        gpu.upload_tree(buf, bounds=bounds)
+        img = gpu.render(cam, w, h, mp)
+        assert np.array_equal(img["hit"], ref["hit"]) and np.array_equal(img["prim"], ref["prim"])
+        assert np.array_equal(bits(img["depth"]), bits(ref["depth"]))
+        assert np.array_equal(bits(img["normal"]), bits(ref["normal"]))
+
+
+@pytest.mark.parametrize("n,seed", [(700, 11), (3000, 12)])
+def test_chain_path_at_size(gpu, n, seed):
+    """Crate-style buffers (PCA trans_inverse in every merged box, obb.rs:183-185) large enough for a deep hierarchy,
+    the candidate grid and many-level chains: nearest, kNN and a frame, bit for bit against the exhaustive oracle and
+    against the library's own exhaustive general path."""
+    buf = pca_scene(n, seed)
+    L = S.default_extent(n)
+    pts = make_points(6000, L, seed)
+    d0, i0 = O.nearest(buf, pts, O.MODE_EXHAUSTIVE, threads=8)
+    info = gpu.upload_tree(buf)
+    assert info.bounds == S.BOUNDS_BVH and info.identity_inner == 0 and info.grid_cells > 0
+    d, i = gpu.nearest(pts)
+    assert np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)
+    kd, ki = gpu.knn(pts[:2000], 8)
+    kd0, ki0 = O.knn(buf, pts[:2000], 8, threads=8)
+    assert np.array_equal(bits(kd), bits(kd0)) and np.array_equal(ki, ki0)
+    w, h = 160, 96
+    cam = S.camera_look_at((0.2 * L, 0.1 * L, -2.5 * L), (0, 0, 0), (0, 1, 0), math.pi / 4, w, h)
+    mp = S.march_params(max_steps=128, eps_hit=1e-3, t_min=0.0, t_max=6 * L, normal_h=1e-4)
+    img = gpu.render(cam, w, h, mp)
+    gpu.upload_tree(buf, bounds=S.BOUNDS_NONE)
+    ref = gpu.render(cam, w, h, mp)                         # the exhaustive general path (itself pinned to the oracle above)
+    assert ref["hit"].sum() > 50
+    for key in ("hit", "prim", "depth", "normal"):
+        assert np.array_equal(np.ascontiguousarray(img[key]).view(np.uint8), np.ascontiguousarray(ref[key]).view(np.uint8)), key
+    sub = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8, pix_first=0, pix_count=w * h // 7, pix_stride=7)
+    sel = np.arange(0, w * h, 7)[: w * h // 7]
+    assert np.array_equal(img["hit"][sel], sub["hit"]) and np.array_equal(bits(img["depth"][sel]), bits(sub["depth"]))
+    assert np.array_equal(img["prim"][sel], sub["prim"]) and np.array_equal(bits(img["normal"][sel]), bits(sub["normal"]))
 
 
 def test_box_bounds_match_the_reference_formulas(gpu):
