@@ -153,7 +153,7 @@ int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const
             return set_err(c, SDFGPU_ERR_TOO_LARGE, "radix sort storage does not fit the static scratch");
         char* base = (char*)c->static_scratch;
         keys_a = (uint32_t*)base;
-        keys_b = (uint32_t*)(base + arr);
+        keys_b = (uint32_t*)(base + arr);        // the sort's 8-byte pairs: this array and the next one
         idx_a = (uint32_t*)(base + 2 * arr);
         idx_b = (uint32_t*)(base + 3 * arr);
         temp = base + 4 * arr;
@@ -161,7 +161,8 @@ int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const
         // the buffers of the stream the batch runs on: batches in flight on different streams do not share them
         sdfgpu_ctx::MarchScratch* ms = stream_scratch(c, s);
         int rc;
-        if ((rc = reserve(c, ms->keys_a, n * 4)) || (rc = reserve(c, ms->keys_b, n * 4)) || (rc = reserve(c, ms->idx_a, n * 4)) ||
+        // keys_b holds the sort's 8-byte (digit, index) pairs (sort.hip); idx_a only serves the SDFGPU_SORT=hipcub comparison path
+        if ((rc = reserve(c, ms->keys_a, n * 4)) || (rc = reserve(c, ms->keys_b, n * 8)) || (rc = reserve(c, ms->idx_a, n * 4)) ||
             (rc = reserve(c, ms->idx_b, n * 4)) || (rc = reserve(c, ms->sort_tmp, tmp)))
             return rc;
         keys_a = (uint32_t*)ms->keys_a.p;
@@ -209,7 +210,7 @@ int ordered_query(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, F&
     const size_t tmp = sort_temp_bytes((uint32_t)chunk);
     for (auto& ps : c->pipe) {
         int rc;
-        if ((rc = reserve(c, ps.keys_a, chunk * 4)) || (rc = reserve(c, ps.keys_b, chunk * 4)) || (rc = reserve(c, ps.idx_a, chunk * 4)) ||
+        if ((rc = reserve(c, ps.keys_a, chunk * 4)) || (rc = reserve(c, ps.keys_b, chunk * 8)) || (rc = reserve(c, ps.idx_a, chunk * 4)) ||
             (rc = reserve(c, ps.idx_b, chunk * 4)) || (rc = reserve(c, ps.tmp, tmp)))
             return rc;
     }

@@ -140,3 +140,49 @@ def test_batches_in_flight_on_several_streams(gpu):
         assert np.array_equal(bits(d1.cpu().numpy()), bits(wd)) and np.array_equal(i1.cpu().numpy().view(np.uint32), wi)
         assert np.array_equal(bits(d8.cpu().numpy().reshape(-1, 8)), bits(wkd))
         assert np.array_equal(i8.cpu().numpy().view(np.uint32).reshape(-1, 8), wki)
+
+
+@pytest.mark.parametrize("shape", ["uniform", "one_cell", "clustered", "outliers", "ragged_small"])
+def test_batch_sort_yields_a_permutation_on_any_distribution(gpu, shape):
+    """The library's own batch sort (sort.hip: two 12-bit digits, buckets cut into chunks when a cell is crowded) must
+    hand the walk a PERMUTATION whatever the distribution: outputs start as a sentinel, so an index that the
+    permutation misses (or repeats, which makes it miss another) shows as an unwritten result."""
+    import torch
+
+    n_prims = 800
+    buf = S.random_scene_buffer(n_prims, 0x50B7)
+    L = S.default_extent(n_prims)
+    gpu.upload_tree(buf)
+    rng = np.random.default_rng(len(shape))
+    n = {"uniform": 300_001, "one_cell": 150_000, "clustered": 400_000, "outliers": 200_000, "ragged_small": 2049}[shape]
+    p = np.ones((n, 4), np.float32)
+    if shape in ("uniform", "ragged_small"):
+        p[:, :3] = rng.uniform(-1.2 * L, 1.2 * L, (n, 3))
+    elif shape == "one_cell":            # every point in one cell of the curve: one bucket, many chunks
+        p[:, :3] = np.float32(0.37 * L) + rng.uniform(0, 1e-3, (n, 3))
+    elif shape == "clustered":           # 90 % of the batch in a ball of 1 % of the scene
+        p[:, :3] = rng.uniform(-1.2 * L, 1.2 * L, (n, 3))
+        m = int(0.9 * n)
+        p[:m, :3] = rng.normal(0.2 * L, 0.01 * L, (m, 3))
+    else:                                # half of the batch far outside the key box: clamped to its border cells
+        p[:, :3] = rng.uniform(-1.2 * L, 1.2 * L, (n, 3))
+        p[::2, :3] *= 40.0
+    pts = torch.from_numpy(p).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for reorder in (True, False):
+        gpu.set_reorder(reorder)
+        d = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+        i = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        gpu.nearest_dev(pts.data_ptr(), n, d.data_ptr(), i.data_ptr(), st)
+        kd = torch.full((n * 4,), -7.0, dtype=torch.float32, device="cuda")
+        ki = torch.full((n * 4,), -7, dtype=torch.int32, device="cuda")
+        gpu.knn_dev(pts.data_ptr(), n, 4, kd.data_ptr(), ki.data_ptr(), st)
+        torch.cuda.synchronize()
+        out[reorder] = tuple(t.cpu().numpy() for t in (d, i, kd, ki))
+    gpu.set_reorder(True)
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (out[True][1] >= 0).all() and (out[True][3] >= 0).all()     # every slot written: no index missed
+    d0, i0 = O.nearest(buf, p[:3000], O.MODE_TUNED, threads=8)
+    assert np.array_equal(bits(out[True][0][:3000]), bits(d0)) and np.array_equal(out[True][1][:3000].view(np.uint32), i0)
