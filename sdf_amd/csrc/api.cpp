@@ -48,6 +48,9 @@ struct sdfgpu_ctx {
         uint32_t order_age = 0;     // frames rendered with the current order while the view stood still
         sdfgpu_camera order_cam{};  // the view the current order was learned from
         uint64_t stamp = 0;         // last use (least recently used entry is recycled)
+        // recorded behind the last work that used this entry's buffers: what recycling waits for (the stream handle
+        // may belong to a stream the caller has destroyed by then; the event is the context's own)
+        hipEvent_t last_use = nullptr;
     };
     std::vector<MarchScratch> march;
     uint64_t march_clock = 0;
@@ -65,6 +68,7 @@ struct sdfgpu_ctx {
     struct PipeSet {
         DevBuf keys_a, keys_b, idx_a, idx_b, tmp;
         hipEvent_t sorted = nullptr, walked = nullptr;
+        bool walked_recorded = false;   // a walk of an earlier call may still read this set
     } pipe[2];
     float skip_ext_opt = 0.f;    // SDFGPU_OPT_SKIP_EXTENSION as set (< 0: half the mean primitive size)
     float mean_extent = 0.f;
@@ -127,6 +131,7 @@ int check_march(sdfgpu_ctx* c, const sdfgpu_camera* cam, uint32_t w, uint32_t h,
 }
 
 sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream);
+void mark_used(sdfgpu_ctx* c, hipStream_t stream);
 
 // Space-filling-curve permutation of a device point batch (nullptr when reordering is off
 // or not worth it).  Scratch is grow-only, so steady-state calls allocate nothing.
@@ -189,7 +194,9 @@ int ordered_query(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, F&
         const uint32_t* order = nullptr;
         int rc = make_order(c, d_pts, n, s, &order);
         if (rc) return rc;
-        return launch(d_pts, order, n, (size_t)0);
+        rc = launch(d_pts, order, n, (size_t)0);
+        if (order) mark_used(c, s);
+        return rc;
     }
     if (!c->aux) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
@@ -214,9 +221,13 @@ int ordered_query(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, F&
             (rc = reserve(c, ps.idx_b, chunk * 4)) || (rc = reserve(c, ps.tmp, tmp)))
             return rc;
     }
-    // the helper stream starts after everything already queued on the caller's stream (the inputs)
+    // the helper stream starts after everything already queued on the caller's stream (the inputs) -- and after the
+    // last walks of an EARLIER pipelined call, which may have run on another caller stream and may still read the
+    // two sets' permutations (two large batches in flight on two streams share the sets)
     HIP_TRY(c, hipEventRecord(c->ev_start, s));
     HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_start, 0));
+    for (auto& ps : c->pipe)
+        if (ps.walked_recorded) HIP_TRY(c, hipStreamWaitEvent(c->aux, ps.walked, 0));
     size_t first = 0;
     for (uint32_t k = 0; first < n; ++k, first += chunk) {
         sdfgpu_ctx::PipeSet& ps = c->pipe[k & 1];
@@ -229,6 +240,7 @@ int ordered_query(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, F&
         int rc = launch(d_pts + 4 * first, (const uint32_t*)ps.idx_b.p, m, first);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(ps.walked, s));
+        ps.walked_recorded = true;
     }
     return SDFGPU_OK;
 }
@@ -269,7 +281,13 @@ sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream) {
         for (size_t i = 1; i < c->march.size(); ++i)
             if (c->march[i].stamp < c->march[lru].stamp) lru = i;
         sdfgpu_ctx::MarchScratch& old = c->march[lru];
-        if (hipStreamSynchronize(old.stream) != hipSuccess) (void)hipDeviceSynchronize();   // the stream may be gone
+        // wait for the entry's own event, not for a stream handle that may be dangling by now
+        if (old.last_use) {
+            if (hipEventSynchronize(old.last_use) != hipSuccess) (void)hipDeviceSynchronize();
+            (void)hipEventDestroy(old.last_use);
+        } else {
+            (void)hipDeviceSynchronize();
+        }
         for (DevBuf* b : {&old.buf, &old.order, &old.eye, &old.keys_a, &old.keys_b, &old.idx_a, &old.idx_b, &old.sort_tmp})
             if (b->p) (void)hipFree(b->p);
         old = sdfgpu_ctx::MarchScratch();
@@ -279,6 +297,16 @@ sdfgpu_ctx::MarchScratch* stream_scratch(sdfgpu_ctx* c, hipStream_t stream) {
     m.stream = stream;
     m.stamp = ++c->march_clock;
     return &m;
+}
+
+// Records "this stream's scratch was last used here" (see MarchScratch::last_use); a no-op for streams without scratch.
+void mark_used(sdfgpu_ctx* c, hipStream_t stream) {
+    for (auto& m : c->march)
+        if (m.stream == stream) {
+            if (!m.last_use && hipEventCreateWithFlags(&m.last_use, hipEventDisableTiming) != hipSuccess) { m.last_use = nullptr; return; }
+            (void)hipEventRecord(m.last_use, stream);
+            return;
+        }
 }
 
 int march_setup(sdfgpu_ctx* c, hipStream_t stream, uint32_t tile_count, uint32_t max_steps, RenderScratch* rs,
@@ -369,6 +397,7 @@ int render_on(sdfgpu_ctx* c, hipStream_t stream, const sdfgpu_camera* cam, uint3
             ms->order_cam = *cam;
         }
     }
+    mark_used(c, stream);
     return SDFGPU_OK;
 }
 
@@ -546,9 +575,11 @@ void sdfgpu_destroy(sdfgpu_ctx* c) {
         if (c->ev_start) (void)hipEventDestroy(c->ev_start);
         (void)hipStreamDestroy(c->aux);
     }
-    for (auto& m : c->march)
+    for (auto& m : c->march) {
         for (DevBuf* b : {&m.buf, &m.order, &m.eye, &m.keys_a, &m.keys_b, &m.idx_a, &m.idx_b, &m.sort_tmp})
             if (b->p) (void)hipFree(b->p);
+        if (m.last_use) (void)hipEventDestroy(m.last_use);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

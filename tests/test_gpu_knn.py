@@ -186,3 +186,41 @@ def test_batch_sort_yields_a_permutation_on_any_distribution(gpu, shape):
     assert (out[True][1] >= 0).all() and (out[True][3] >= 0).all()     # every slot written: no index missed
     d0, i0 = O.nearest(buf, p[:3000], O.MODE_TUNED, threads=8)
     assert np.array_equal(bits(out[True][0][:3000]), bits(d0)) and np.array_equal(out[True][1][:3000].view(np.uint32), i0)
+
+
+def test_chunked_pipeline_with_two_caller_streams(gpu):
+    """Two large batches in flight on two caller streams with SDFGPU_OPT_QUERY_PIPELINE on share the context's two
+    pipeline sets and its helper stream: the helper must not re-sort a set while the OTHER stream's walk still reads
+    its permutation (it waits for both sets' last walks before the first sort of a call)."""
+    import torch
+    from sdf_amd import _ffi
+
+    n_prims, n = 1500, (1 << 20) + 777
+    buf = S.random_scene_buffer(n_prims, 0x2577)
+    gpu.upload_tree(buf)
+    L = S.default_extent(n_prims)
+    sets = [torch.from_numpy(make_points(n, L, seed=900 + j)).cuda() for j in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    want = []
+    for p in sets:
+        d = torch.empty(n, dtype=torch.float32, device="cuda")
+        i = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.nearest_dev(p.data_ptr(), n, d.data_ptr(), i.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want.append((d, i))
+    try:
+        gpu.set_option(_ffi.OPT_QUERY_PIPELINE, 3)
+        outs = []
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for j, (p, st) in enumerate(zip(sets, streams)):
+                d = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+                i = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize() if rep == 0 and j == 0 else None
+                gpu.nearest_dev(p.data_ptr(), n, d.data_ptr(), i.data_ptr(), st.cuda_stream)
+                outs.append((j, d, i))
+        torch.cuda.synchronize()
+    finally:
+        gpu.set_option(_ffi.OPT_QUERY_PIPELINE, 0)
+    for j, d, i in outs:
+        assert torch.equal(d.view(torch.int32), want[j][0].view(torch.int32)) and torch.equal(i, want[j][1])

@@ -79,3 +79,26 @@ def test_clone_subtree_as_written():
     assert np.array_equal(bits(got), bits(want))
     d, _ = R.nearest_exhaustive(buf, pts)
     assert np.array_equal(bits(d), bits(want))
+
+
+def test_reference_result_beyond_the_query_domain_is_recorded():
+    """Recorded deviation (sdfgpu.h "Domain of a query point"): for a FINITE point with a
+    coordinate beyond 2^62 the library returns (NaN, SDF_NO_PRIM); the reference's literal fold returns whatever its
+    overflowed arithmetic leaves.  This test keeps that literal result visible instead of restating the library's
+    rule on both sides: both restatements run the state machine of faux_shader.rs:96-208 as written at such points
+    and must agree with each other; the value is +inf or NaN (inf - inf after an overflowing product), or, where
+    nothing overflowed yet, an ordinary huge distance -- never something the library's rule would contradict inside
+    the domain."""
+    import warnings
+    buf = S.random_scene_buffer(9, 0xD0)
+    pts = np.array([[3e38, 0, 0, 1], [0, -2e30, 5e18, 1], [1e25, 1e25, -1e25, 1], [5e18, 5e18, 5e18, 1]], np.float32)
+    assert (np.abs(pts[:, :3]).max(axis=1) > 2.0 ** 62).all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with np.errstate(all="ignore"):
+            want = [R.faux_nearest_scalar(buf, p) for p in pts]
+    got, _ = O.nearest(buf, pts, O.MODE_FAUX)
+    for d, g in zip(want, got):
+        d = np.float32(d)
+        assert (np.isnan(d) and np.isnan(g)) or bits(np.array([d]))[0] == bits(np.array([g]))[0]
+        assert np.isnan(g) or np.isinf(g) or g > 2.0 ** 61
