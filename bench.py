@@ -809,6 +809,19 @@ def main():
                      "HIP events on the launch stream, outside the timed region",
                 traffic=traffic, traffic_note=traffic_note)
             line["roofline"]["frac_at_throughput"] = W.algorithmic_flops_needed(st) / (ms * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS
+            if int(info.grid_cells) > 0:
+                # The candidate grid (round 3) removed most of the algorithm's own work, so `frac` fell while the frame
+                # got faster.  For continuity with rounds 1-2: the same frame's work as the walk-only algorithm does it
+                # (counting kernel of a context without the grid) over THIS kernel's time.  Not the kernel's roofline.
+                g0 = S.SdfGpu(local_rank)
+                g0.set_candidate_grid(False)
+                g0.upload_tree(buf, bounds=bounds)
+                st0 = g0.render_stats(cam, w, h, mp)
+                g0.close()
+                f0 = W.algorithmic_flops_needed(st0)
+                line["roofline"]["frac_at_round2_work"] = f0 / (k_avg * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS
+                line["roofline"]["round2_work_note"] = (f"{f0 / 1e9:.2f} Gflop = needed-lane work of the same frame without the candidate grid "
+                                                        "(walks on every uncertified step, as in rounds 1-2) / kernel_ms_avg; continuity only")
             line["work"] = {
                 "steps_per_ray": st["steps"] / max(1, st["rays"]),
                 "walks_per_ray": st["queries"] / max(1, st["rays"]),
@@ -820,6 +833,10 @@ def main():
                 "wave_inner_visits": st["wave_inner"], "wave_leaf_visits": st["wave_leaf"],
                 "queries": st["queries"],
                 "needed_over_issued_lane_slots": st["inner_needed"] / max(1, 64 * st["wave_inner"]),
+                "list_steps_per_ray": st["list_steps"] / max(1, st["rays"]),
+                "wave_list_passes": st["wave_lists"], "wave_list_evals": st["wave_list_evals"],
+                "evals_per_list_pass": st["wave_list_evals"] / max(1, st["wave_lists"]),
+                "lanes_advancing_per_iteration": st["steps"] / max(1, st["wave_steps"]),
             }
             if not a.no_variants:
                 line["variants"] = variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev)

@@ -441,6 +441,7 @@ static void wave_step_grid(Lane* L, Stats& st, GridStats& gs, int policy) {
     }
     if (nalive == 0) return;
     st.wave_steps++;
+    st.by_alive_steps[nalive]++;
     gs.iters++;
     const bool lists_go = nlist > 0 && !(policy == 1 && ncert > 0);
     const bool do_walk = nwalk > 0 && ncert == 0 && nlist == 0;
