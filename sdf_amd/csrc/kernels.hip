@@ -788,11 +788,19 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
     return ((l / chunk) * 8u + x) * chunk + l % chunk;
 }
 
+template <int MODE, bool COUNT, bool CHAIN>
+__device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py, float pz, float mg, bool active, uint32_t lane,
+                                          float& best, uint32_t& bid, float& budget, bool& adv, WaveCounters& wc);
+
 // ----------------------------------------------------------- K1: nearest --
 // faux_shader::nearest_neighbor (faux_shader.rs:96-208) for n points, plus
 // the primitive index.  One point per lane.  `order` (optional) is a
 // permutation that makes consecutive lanes spatially close (Morton order);
 // results are written at the original index.
+// A point that lies in a cell of the nearest-candidate grid with a list (kernels.hpp CandidateGrid: built for the
+// march, but what a cell's list proves -- it holds every primitive that can attain or tie for the minimum anywhere in
+// the cell -- is a statement about points, not about rays) is decided on that list, exactly; the wavefront walks the
+// tree only for its remaining lanes (outside the padded scene box, cells without a list), if there are any.
 template <int MODE, int COUNT, bool CHAIN = false>
 __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* __restrict__ pts,
                                                       const uint32_t* __restrict__ order, uint32_t n,
@@ -813,9 +821,16 @@ __global__ __launch_bounds__(256) void nearest_kernel(TreeView T, const float4* 
     WaveCounters wc;
     AccNearest acc{best, bid};
     const bool in_dom = in_domain3(p.x, p.y, p.z);
-    nn_traverse<MODE, COUNT, true, CHAIN>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
-    best = in_dom ? acc.best : __builtin_nanf("");
-    bid = in_dom ? acc.bid : SDF_NO_PRIM;
+    bool listed = false;
+    if constexpr (COUNT == 0) {   // (the counting instantiations count the walk)
+        float budget = 0.f;
+        bool took = false;
+        if (list_pass<MODE, false, CHAIN>(T, p.x, p.y, p.z, 0.f, alive && in_dom, lane, best, bid, budget, took, wc)) listed = took;
+    }
+    const unsigned long long drive = __builtin_amdgcn_ballot_w64(alive && in_dom && !listed);
+    if (drive != 0ull) nn_traverse<MODE, COUNT, true, CHAIN>(T, p.x, p.y, p.z, drive, 0.f, acc, stk, lane, wc);
+    best = in_dom ? (listed ? best : acc.best) : __builtin_nanf("");
+    bid = in_dom ? (listed ? bid : acc.bid) : SDF_NO_PRIM;
     if (alive) {
         out_dist[src] = best;
         if (out_prim) out_prim[src] = bid;
