@@ -463,11 +463,13 @@ int build_grid(sdfgpu_ctx* c, const CompactTree& t) {
     const float margin = 8.0f * e_max;
     const size_t cells_bytes = (cells * sizeof(GridCell) + 63u) & ~(size_t)63u;
     const size_t ids_bytes = bricks * GRID_BRICK_IDS * sizeof(uint32_t);
-    g.bytes = sizeof(GridBlock) + cells_bytes + ids_bytes;
+    const size_t caps_bytes = cells * sizeof(GridCap);
+    g.bytes = sizeof(GridBlock) + cells_bytes + ids_bytes + caps_bytes;
     if (g.bytes >= (1ull << 32)) return SDFGPU_OK;   // the march addresses the tables with 32-bit offsets
     if (hipMalloc(&g.block, g.bytes) != hipSuccess) { (void)hipGetLastError(); return SDFGPU_OK; }
     g.cells = (GridCell*)((char*)g.block + sizeof(GridBlock));
     g.brick_ids = (uint32_t*)((char*)g.block + sizeof(GridBlock) + cells_bytes);
+    g.caps = (GridCap*)((char*)g.block + sizeof(GridBlock) + cells_bytes + ids_bytes);
     const uint32_t chunk = (uint32_t)std::min<uint64_t>(bricks, 16384);   // 1 M cells per round: 144 MB of centres and rows
     void* temp = nullptr;
     if (hipMalloc(&temp, grid_temp_bytes(chunk)) != hipSuccess) {
@@ -480,6 +482,7 @@ int build_grid(sdfgpu_ctx* c, const CompactTree& t) {
     gb.nbx = g.n[0] / 4u;
     gb.nby = g.n[1] / 4u;
     gb.bricks_off = (uint32_t)(sizeof(GridBlock) + cells_bytes);
+    gb.caps_off = (uint32_t)(sizeof(GridBlock) + cells_bytes + ids_bytes);
     if (hipMemcpy(g.block, &gb, sizeof gb, hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(temp);

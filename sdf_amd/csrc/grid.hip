@@ -25,6 +25,8 @@ extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);
 
 namespace sdfgpu {
 
+static_assert(GRID_CELL_K == 16, "GridCap keeps the 8th and the 16th of a cell's GRID_CELL_K rows");
+
 // centre of cell `lane` of brick b: bricks are numbered x fastest, cells inside a brick likewise
 __global__ __launch_bounds__(256) void grid_centres_kernel(uint32_t brick0, uint32_t n_bricks, uint32_t nbx, uint32_t nby,
                                                            float lox, float loy, float loz, float cx, float cy, float cz,
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256) void grid_centres_kernel(uint32_t brick0, uint
 // ascending id order by repeated wave-wide minimum; more than GRID_BRICK_IDS entries: no lists in the brick.
 __global__ __launch_bounds__(256) void grid_brick_kernel(uint32_t brick0, uint32_t n_bricks, uint32_t n_leaf,
                                                          const float* __restrict__ rows_d, const uint32_t* __restrict__ rows_i,
-                                                         float list_span, float lb_add, GridCell* __restrict__ cells,
-                                                         uint32_t* __restrict__ brick_ids) {
+                                                         float list_span, float lb_add, float cap_add, GridCell* __restrict__ cells,
+                                                         uint32_t* __restrict__ brick_ids, GridCap* __restrict__ caps) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t bl = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (bl >= n_bricks) return;
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(256) void grid_brick_kernel(uint32_t brick0, uint32
     c.mask = (overflow || !listed) ? 0u : mask;
     c.lb = d0 + lb_add;
     cells[(size_t)(brick0 + bl) * 64u + lane] = c;
+    // k-nearest radius caps: each of the j nearest at the centre is within d[j-1] + lip r + rounding of any point of the cell
+    GridCap q;
+    const float inf = __builtin_inff();
+    q.d8 = (id[7] != SDF_NO_PRIM && d[7] == d[7]) ? d[7] + cap_add : inf;
+    q.d16 = (id[GRID_CELL_K - 1] != SDF_NO_PRIM && d[GRID_CELL_K - 1] == d[GRID_CELL_K - 1]) ? d[GRID_CELL_K - 1] + cap_add : inf;
+    caps[(size_t)(brick0 + bl) * 64u + lane] = q;
 }
 
 size_t grid_temp_bytes(uint32_t chunk_bricks) {
@@ -109,6 +117,7 @@ hipError_t build_candidate_grid(const DeviceTree& d, float cell_radius_inflated,
     if (n_bricks == 0 || chunk_bricks == 0) return hipSuccess;
     const float list_span = 2.0f * d.lipschitz * cell_radius_inflated + list_margin;
     const float lb_add = d.lipschitz * cell_radius_inflated;
+    const float cap_add = lb_add + list_margin;
     char* base = (char*)temp;
     float4* pts = (float4*)base;
     float* rows_d = (float*)(base + (size_t)chunk_bricks * 64u * sizeof(float4));
@@ -125,7 +134,7 @@ hipError_t build_candidate_grid(const DeviceTree& d, float cell_radius_inflated,
         // cells of a brick are consecutive points: one wavefront of the query walks for one brick
         e = launch_knn(walk, (const float*)pts, nullptr, nb * 64u, GRID_CELL_K, rows_d, rows_i, nullptr, s);
         if (e != hipSuccess) return e;
-        grid_brick_kernel<<<grid, block, 0, s>>>((uint32_t)b0, nb, d.n_leaf, rows_d, rows_i, list_span, lb_add, g.cells, g.brick_ids);
+        grid_brick_kernel<<<grid, block, 0, s>>>((uint32_t)b0, nb, d.n_leaf, rows_d, rows_i, list_span, lb_add, cap_add, g.cells, g.brick_ids, g.caps);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -863,6 +863,7 @@ template <int K>
 struct AccK {
     static constexpr bool TRACKS = false;
     unsigned long long key[K];
+    float cap = __builtin_inff();
     __device__ __forceinline__ void init() {
         const unsigned long long pad = ((unsigned long long)ord_f32(__builtin_inff()) << 32) | 0xFFFFFFFFull;
 #pragma unroll
@@ -878,7 +879,7 @@ struct AccK {
         const uint32_t lo = (uint32_t)key[j];
         return lo == 0xFFFFFFFFu ? SDF_NO_PRIM : 0xFFFFFFFEu - lo;
     }
-    __device__ __forceinline__ float radius() const { return dist(K - 1); }
+    __device__ __forceinline__ float radius() const { return __builtin_fminf(dist(K - 1), cap); }
     __device__ __forceinline__ void skipped(float) {}
     __device__ __forceinline__ void offer(float nd, uint32_t nid) {
         const unsigned long long cur = ((unsigned long long)ord_f32(nd) << 32) | (unsigned long long)(0xFFFFFFFEu - nid);
@@ -916,6 +917,27 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     acc.init();
     WaveCounters wc;
     const bool in_dom = in_domain3(p.x, p.y, p.z);
+    // A point inside the candidate grid starts with the prune radius capped at its cell's bound on the K-th nearest
+    // distance (GridCap) instead of +inf: everything that can be among its K nearest, ties included, lies within it,
+    // so the result is the same and the first descents no longer wander through subtrees a converged radius would
+    // have skipped (caller-sorted k = 8 batch 1.126 -> ~1.0 ms; the exact final radius as the cap would give 0.90).
+    if constexpr (MODE != SDFGPU_BOUNDS_OBB) {
+        if (T.gblock != nullptr) {
+            const f32x16 G = load_rec64_s48(T.gblock, 0u);
+            const float gx = __builtin_fminf(__builtin_fmaxf((p.x - G[0]) * G[3], -1.f), 65536.f);
+            const float gy = __builtin_fminf(__builtin_fmaxf((p.y - G[1]) * G[4], -1.f), 65536.f);
+            const float gz = __builtin_fminf(__builtin_fmaxf((p.z - G[2]) * G[5], -1.f), 65536.f);
+            const uint32_t ix = (uint32_t)(int)__builtin_floorf(gx), iy = (uint32_t)(int)__builtin_floorf(gy), iz = (uint32_t)(int)__builtin_floorf(gz);
+            const bool in = alive && in_dom && ix < rec_bits(G[6]) && iy < rec_bits(G[7]) && iz < rec_bits(G[8]);
+            const uint32_t bi = ((iz >> 2) * rec_bits(G[10]) + (iy >> 2)) * rec_bits(G[9]) + (ix >> 2);
+            const uint32_t caps_off = rec_bits(G[12]);
+            if (in) {
+                const GridCap q = *reinterpret_cast<const GridCap*>(reinterpret_cast<const char*>(T.gblock) + caps_off +
+                                                                    (size_t)(((bi << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)) << 3));
+                acc.cap = K <= 8 ? q.d8 : q.d16;
+            }
+        }
+    }
     nn_traverse<MODE, COUNT, true, CHAIN>(T, p.x, p.y, p.z, __builtin_amdgcn_ballot_w64(alive && in_dom), 0.f, acc, stk, lane, wc);
     if (!in_dom) acc.init_nan();
     if (alive) {

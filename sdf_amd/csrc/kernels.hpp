@@ -19,13 +19,20 @@ struct GridCell {
     uint32_t mask;
     float lb;
 };
+// Upper bounds, valid anywhere in the cell, on the distance of a point's 8th- and 16th-nearest primitive (the values
+// at the cell's centre + lip r + M, by the same Lipschitz argument): the k-nearest query starts its walk with the
+// prune radius capped there instead of at +inf (+inf: the tree has fewer primitives than that).
+struct GridCap {
+    float d8, d16;
+};
 constexpr uint32_t GRID_BRICK_IDS = 32;   // entries of a brick's candidate list (one mask bit each)
 constexpr uint32_t GRID_CELL_K = 16;      // candidates looked at per cell (the K of the k-nearest query that builds it)
 struct CandidateGrid {
-    // ONE allocation: [GridBlock | cells | brick ids].  The march addresses both tables relative to `block` (a
+    // ONE allocation: [GridBlock | cells | brick ids | caps].  The march addresses both tables relative to `block` (a
     // pointer pair it holds anyway), which is worth two SGPRs it does not have to spare.
     GridCell* cells = nullptr;      // [bricks][64], cell (x, y, z) of a brick at (z & 3) << 4 | (y & 3) << 2 | (x & 3)
     uint32_t* brick_ids = nullptr;  // [bricks][GRID_BRICK_IDS]
+    GridCap* caps = nullptr;        // [bricks][64], as cells
     float lo[3] = {0.f, 0.f, 0.f};
     float inv_cell[3] = {0.f, 0.f, 0.f};
     uint32_t n[3] = {0, 0, 0};      // cells per axis (multiples of 4)
@@ -39,7 +46,8 @@ struct alignas(64) GridBlock {
     uint32_t n[3];
     uint32_t nbx, nby;              // bricks per axis (x, y)
     uint32_t bricks_off;            // byte offset of the brick id table from this block (the cells follow the block directly)
-    uint32_t pad[4];
+    uint32_t caps_off;              // byte offset of the k-nearest radius caps
+    uint32_t pad[3];
 };
 static_assert(sizeof(GridBlock) == 64, "GridBlock is one 64-byte scalar load");
 
