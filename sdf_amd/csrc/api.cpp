@@ -478,7 +478,7 @@ int build_grid(sdfgpu_ctx* c, const CompactTree& t) {
         return SDFGPU_OK;
     }
     GridBlock gb{};
-    for (int a = 0; a < 3; ++a) { gb.lo[a] = g.lo[a]; gb.inv_cell[a] = g.inv_cell[a]; gb.n[a] = g.n[a]; }
+    for (int a = 0; a < 3; ++a) { gb.lo[a] = g.lo[a]; gb.inv_cell[a] = g.inv_cell[a]; gb.n[a] = g.n[a]; gb.cell[a] = 1.0f / g.inv_cell[a]; }
     gb.nbx = g.n[0] / 4u;
     gb.nby = g.n[1] / 4u;
     gb.bricks_off = (uint32_t)(sizeof(GridBlock) + cells_bytes);

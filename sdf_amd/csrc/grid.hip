@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void grid_brick_kernel(uint32_t brick0, uint32
     c.mask = (overflow || !listed) ? 0u : mask;
     c.lb = d0 + lb_add;
     cells[(size_t)(brick0 + bl) * 64u + lane] = c;
-    // k-nearest radius caps: each of the j nearest at the centre is within d[j-1] + lip r + rounding of any point of the cell
+    // k-nearest radius caps (kernels.hpp GridCap)
     GridCap q;
     const float inf = __builtin_inff();
     q.d8 = (id[7] != SDF_NO_PRIM && d[7] == d[7]) ? d[7] + cap_add : inf;
@@ -117,7 +117,7 @@ hipError_t build_candidate_grid(const DeviceTree& d, float cell_radius_inflated,
     if (n_bricks == 0 || chunk_bricks == 0) return hipSuccess;
     const float list_span = 2.0f * d.lipschitz * cell_radius_inflated + list_margin;
     const float lb_add = d.lipschitz * cell_radius_inflated;
-    const float cap_add = lb_add + list_margin;
+    const float cap_add = list_margin;   // the query adds lip |p - c| itself
     char* base = (char*)temp;
     float4* pts = (float4*)base;
     float* rows_d = (float*)(base + (size_t)chunk_bricks * 64u * sizeof(float4));

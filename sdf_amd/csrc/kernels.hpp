@@ -19,9 +19,10 @@ struct GridCell {
     uint32_t mask;
     float lb;
 };
-// Upper bounds, valid anywhere in the cell, on the distance of a point's 8th- and 16th-nearest primitive (the values
-// at the cell's centre + lip r + M, by the same Lipschitz argument): the k-nearest query starts its walk with the
-// prune radius capped there instead of at +inf (+inf: the tree has fewer primitives than that).
+// The 8th- and 16th-nearest value at the cell's centre c, plus the rounding margin M.  Each of the j nearest primitives
+// at c is within d_j(c) + lip |p - c| + rounding of a point p, so d_j(c) + M + lip |p - c| bounds the distance of p's
+// j-th nearest primitive from above: the k-nearest query starts its walk with the prune radius capped there instead
+// of at +inf (+inf here: the tree has fewer primitives than that).
 struct GridCap {
     float d8, d16;
 };
@@ -47,7 +48,7 @@ struct alignas(64) GridBlock {
     uint32_t nbx, nby;              // bricks per axis (x, y)
     uint32_t bricks_off;            // byte offset of the brick id table from this block (the cells follow the block directly)
     uint32_t caps_off;              // byte offset of the k-nearest radius caps
-    uint32_t pad[3];
+    float cell[3];                  // cell size per axis (1 / inv_cell as the build computed it: cell centres are lo + (i + 0.5) * cell)
 };
 static_assert(sizeof(GridBlock) == 64, "GridBlock is one 64-byte scalar load");
 
