@@ -159,8 +159,11 @@ int sdfgpu_upload_tree(sdfgpu_ctx* ctx, const SdfOperationBlock* dt,
  *   BOX_FRAME     primitive op 5 is accepted: iq's box-frame distance of (dimension, thickness)
  *   CLONE_REPAIR  uptree op 1 returns the LEFT branch (the one the clone's slot filled), so the lattice
  *                 fold of downtree op 1 (faux_shader.rs:75-78) takes effect
- * A tree in which an enabled extension occurs is evaluated exhaustively (bounds NONE, the general
- * path): O(nodes) per query.  Restated by oracle/oracle.cpp under oracle_set_extensions. */
+ * A tree in which an enabled extension occurs takes the general path (reported as bounds NONE: the buffer's
+ * topology with the reference's post-order combine).  Where every map of the tree is affine and rigid -- anything
+ * the crate's builder emits -- its walks skip subtrees on boxes the library derives itself, bit-identical to the
+ * exhaustive walk (from 256 resident nodes on, and unless the smooth radii are of the order of the scene);
+ * otherwise it is exhaustive, O(nodes) per query.  Restated by oracle/oracle.cpp under oracle_set_extensions. */
 typedef enum sdfgpu_extension {
     SDFGPU_EXT_SMOOTH_UNION = 1,
     SDFGPU_EXT_BOX_FRAME = 2,

@@ -138,7 +138,7 @@ void mark_used(sdfgpu_ctx* c, hipStream_t stream);
 constexpr size_t REORDER_MIN_POINTS = 2048;
 int make_order(sdfgpu_ctx* c, const float* d_pts, size_t n, hipStream_t s, const uint32_t** order, bool use_static = false) {
     *order = nullptr;
-    if (!c->reorder || n < REORDER_MIN_POINTS || c->tree.gen) return SDFGPU_OK;
+    if (!c->reorder || n < REORDER_MIN_POINTS || (c->tree.gen && !c->tree.gen_prune)) return SDFGPU_OK;   // (an exhaustive walk visits everything in any order)
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
         // twice the scene box: queries usually sit around the scene; outliers are clamped
@@ -639,6 +639,7 @@ int sdfgpu_upload_tree_ext(sdfgpu_ctx* c, const SdfOperationBlock* dt, const Sdf
     }
     c->tree.n_gen = (uint32_t)t.gen.size();
     c->tree.gen_eval = t.gen_eval;
+    c->tree.gen_prune = t.gen_prune;
     c->tree.root_ref = t.root_ref;
     c->tree.n_leaf = (uint32_t)t.leaves.size();
     c->tree.stack_depth = t.stack_depth;

@@ -63,11 +63,11 @@ constexpr uint32_t GEN_OP_UNION = 0, GEN_OP_CLONE = 1;
 struct alignas(64) GpuGenNode {
     float m[16];       // trans_inverse, column-major as in the buffer
     float param[4];    // sphere: radius; box: half extents; box frame: dimension + thickness
-    uint32_t kind;     // primitive kind (leaves)
+    uint32_t kind;     // leaves: primitive kind; internal nodes: number of primitives in the subtree
     uint32_t is_leaf;
     uint32_t level;    // root = 1
-    uint32_t prim;     // primitive id (leaves)
-    uint32_t len;
+    uint32_t prim;     // leaves: primitive id; internal nodes: the first primitive id of the subtree
+    uint32_t skip_to;  // index of the first node behind this node's subtree (pruned walks jump there)
     // evaluation with the real post-order combine (extensions; walk_eval in kernels.hip)
     uint32_t slot;     // which of its parent's two results this node writes (child ordinal in the buffer)
     uint32_t parent;   // index of the parent in this array (REF_NONE for the root)
@@ -75,7 +75,14 @@ struct alignas(64) GpuGenNode {
     uint32_t op;       // internal nodes: GEN_OP_*
     float smooth_k;    // union: smooth radius in effect (0 = plain min)
     float clone[9];    // clone: displacement, neg_limit, pos_limit (xyz each)
-    uint32_t pad[9];
+    // pruned evaluation (walk_eval_pruned; CompactTree::gen_prune): everything below this node lies inside the box
+    // bc +- bh IN THE FRAME OF THE POINT ITS PARENT HANDS DOWN (world for plain unions; the folded frame below a
+    // clone; the re-based frame below a node with its own trans_inverse), so outside the box the subtree's value is at
+    // least the distance to it minus `slack` (what the smooth unions inside can take off a minimum: k/4 per level)
+    float bc[3], bh[3];
+    float slack;
+    uint32_t up_skip;  // proper ancestors whose subtree ends where this node's does: combined right after it when it is skipped
+    float parent_k;    // smooth radius in effect at the parent (0: plain minimum, clone, or no parent)
 };
 static_assert(sizeof(GpuGenNode) == 192, "GpuGenNode is three 64-byte lines");
 
@@ -98,6 +105,7 @@ struct CompactTree {
     uint32_t chain_max = 0;
     std::vector<GpuGenNode> gen;        // general path (empty otherwise)
     bool gen_eval = false;              // general path must run the post-order combine (a smooth union is in effect)
+    bool gen_prune = false;             // general path: every node carries a valid box (rigid affine maps throughout): the walks prune
     std::vector<GpuLeaf> leaves;
     std::vector<GpuInner> inner;        // AABB mode
     std::vector<GpuInnerObb> inner_obb; // OBB mode

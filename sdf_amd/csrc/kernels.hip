@@ -1579,6 +1579,8 @@ struct EvalStacks {
     float4* pt;     // [levels + 1][64]
     float2* d;      // [levels + 2][64]
     uint2* id;      // [levels + 2][64]
+    float* cut;     // [levels + 2][64] (walk_eval_pruned)
+    uint32_t* ctl;  // [64]: per level, the child that waits (pruned walks)
 };
 __device__ __forceinline__ void walk_eval(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, const EvalStacks& S,
                                           uint32_t lane, float& out_d, uint32_t& out_id) {
@@ -1648,18 +1650,267 @@ __device__ __forceinline__ EvalStacks eval_stacks(float4* base, uint32_t levels)
     S.pt = base;
     S.d = reinterpret_cast<float2*>(base + (size_t)(levels + 1u) * 64u);
     S.id = reinterpret_cast<uint2*>(S.d + (size_t)(levels + 2u) * 64u);
+    S.cut = reinterpret_cast<float*>(S.id + (size_t)(levels + 2u) * 64u);
+    S.ctl = nullptr;   // set by the kernel (the control stack sits at the end of the block's LDS)
     return S;
+}
+
+// ---- pruned walks of the general path (round 3) ----------------------------------------------------------------
+// compact.cpp (gen_prune_data) gives every resident node a box IN THE FRAME OF THE POINT ITS PARENT HANDS DOWN -- world
+// below plain unions, the folded frame below a clone, the re-based frame below a node with a trans_inverse of its own --
+// and `slack`, what the smooth unions inside the subtree can take off the minimum of its leaves (k/4 per level).  For a
+// handed-down point q OUTSIDE the box the subtree's value is therefore at least dist(q, box) - slack, and the walks
+// below skip a subtree (jump to skip_to) when that bound shows, for every lane of the wavefront, that the subtree's
+// exact value cannot matter.  A skipped subtree leaves +inf in its slot, which is what the frames are initialised
+// with (faux_shader.rs:177); a lane that did not need a subtree its wavefront visits anyway simply gets the exact value.
+// The bound, rounded down: the hardware square root and the subtraction lose 1e-6 relative at most, and a leaf value's
+// own rounding is of the order 1e-6 (|q|_1 + T) (prune_margin); 2e-5 relative and 2e-5 (|q|_1 + T) absolute cover both.
+__device__ __forceinline__ float gen_lower_bound(const GpuGenNode* __restrict__ N, float4 q, float scene_T) {
+    const float dx = __builtin_fmaxf(__builtin_fabsf(q.x - N->bc[0]) - N->bh[0], 0.f);
+    const float dy = __builtin_fmaxf(__builtin_fabsf(q.y - N->bc[1]) - N->bh[1], 0.f);
+    const float dz = __builtin_fmaxf(__builtin_fabsf(q.z - N->bc[2]) - N->bh[2], 0.f);
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (!(d2 > 0.f)) return -__builtin_inff();   // inside the box (or not a number): no bound
+    const float d = __builtin_amdgcn_sqrtf(d2);
+    return (d * 0.99998f - N->slack) - 2.0e-5f * ((__builtin_fabsf(q.x) + __builtin_fabsf(q.y)) + (__builtin_fabsf(q.z) + scene_T));
+}
+
+// Both pruned walks are depth-first with the NEARER child first (by the bound of the wavefront's first live lane): the
+// near subtree usually holds the minimum, and once it is known exactly the far one faces a tight radius / cut.  The
+// child that waits is kept per level in `ctl` (wave-uniform, LDS; every lane writes the same value).
+//
+// walk_general with skipping.  only == SDF_NO_PRIM for every lane (`any_only` false): a subtree is skipped when its
+// bound exceeds every live lane's prune radius (strictly: a tie could still win on the index).  Otherwise (normal
+// taps): a subtree is visited only if it holds the primitive some lane asks for (primitive ids are pre-order
+// ordinals, so a subtree holds a contiguous range of them).
+template <class Acc>
+__device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, uint32_t only, bool any_only,
+                                                    bool live, float scene_T, Acc& acc, float4* __restrict__ stk,
+                                                    uint32_t* __restrict__ ctl, uint32_t lane) {
+    stk[lane] = make_float4(p.x, p.y, p.z, p.w);
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+    if (lm == 0ull || n == 0u) return;
+    const int lead = (int)__builtin_ctzll(lm);
+    uint32_t i = 0;
+    for (;;) {
+        const GpuGenNode* __restrict__ N = nodes + i;
+        const uint32_t lv = N->level;
+        const float4 q4 = stk[(lv - 1u) * 64u + lane];
+        bool want;
+        if (any_only) {
+            const uint32_t first = N->prim, cnt = N->is_leaf ? 1u : N->kind;
+            want = live && only != SDF_NO_PRIM && (only - first) < cnt;
+        } else {
+            want = live && !(gen_lower_bound(N, q4, scene_T) > acc.radius());
+        }
+        bool descended = false;
+        if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+            const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+            if (N->is_leaf) {
+                const float d = prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
+                if (only == SDF_NO_PRIM || only == N->prim) acc.offer(d, N->prim);
+            } else {
+                const P4 c = down_point(N, r);
+                const float4 c4 = make_float4(c.x, c.y, c.z, c.w);
+                stk[lv * 64u + lane] = c4;
+                const uint32_t k0 = i + 1u;
+                if (k0 < N->skip_to) {
+                    const uint32_t k1 = nodes[k0].skip_to;
+                    uint32_t first = k0, second = REF_NONE;
+                    if (k1 < N->skip_to) {
+                        const float b0 = gen_lower_bound(nodes + k0, c4, scene_T), b1 = gen_lower_bound(nodes + k1, c4, scene_T);
+                        const uint32_t pick1 = (uint32_t)__builtin_amdgcn_readlane((int)((b1 < b0) ? 1u : 0u), lead);
+                        first = pick1 ? k1 : k0;
+                        second = pick1 ? k0 : k1;
+                    }
+                    ctl[lv] = second;
+                    i = first;
+                    descended = true;
+                }
+            }
+        }
+        if (descended) continue;
+        // node i is done: its parent's waiting child next, or the parent is done as well
+        for (;;) {
+            const uint32_t P = nodes[i].parent;
+            if (P == REF_NONE) return;
+            const uint32_t lp = nodes[P].level;
+            const uint32_t j = ctl[lp];
+            if (j != REF_NONE) { ctl[lp] = REF_NONE; i = j; break; }
+            i = P;
+        }
+    }
+}
+
+// An upper bound on the root's value for every lane: the value of ONE primitive, reached by descending from the root
+// into the child whose box the first live lane's point is nearer to (the lanes of a wavefront are neighbours).  A
+// union, plain or smooth, never exceeds any of its operands' values, a repaired clone hands its one operand's up.
+__device__ __forceinline__ float gen_seed_value(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, bool live, float scene_T,
+                                                float4* __restrict__ pt, uint32_t lane) {
+    pt[lane] = make_float4(p.x, p.y, p.z, p.w);
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+    if (lm == 0ull || n == 0u) return __builtin_inff();
+    const int lead = (int)__builtin_ctzll(lm);
+    uint32_t i = 0;
+    for (;;) {
+        const GpuGenNode* __restrict__ N = nodes + i;
+        const uint32_t lv = N->level;
+        const float4 q4 = pt[(lv - 1u) * 64u + lane];
+        const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+        if (N->is_leaf) return prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
+        const P4 c = down_point(N, r);
+        const float4 c4 = make_float4(c.x, c.y, c.z, c.w);
+        pt[lv * 64u + lane] = c4;
+        const uint32_t k0 = i + 1u;
+        if (k0 >= N->skip_to) return __builtin_inff();   // nothing live below
+        const uint32_t k1 = nodes[k0].skip_to;
+        uint32_t next = k0;
+        if (k1 < N->skip_to) {
+            const float b0 = gen_lower_bound(nodes + k0, c4, scene_T), b1 = gen_lower_bound(nodes + k1, c4, scene_T);
+            const uint32_t pick1 = (uint32_t)__builtin_amdgcn_readlane((int)((b1 < b0) ? 1u : 0u), lead);
+            next = pick1 ? k1 : k0;
+        }
+        i = next;
+    }
+}
+
+// walk_eval with skipping.  Every node is visited with a CUT: its exact value is needed only if it is below the cut;
+// above it any value >= the cut will do (+inf, when the subtree is skipped).  Contract of a visit, by induction over
+// the tree: the slot holds v exactly if v < cut, and something >= cut otherwise.
+//   root: cut = an upper bound on the root's value (gen_seed_value), a little inflated: the root is exact.
+//   children of a node with cut c and smooth radius k (0: plain minimum): v = min(a, b) - f, 0 <= f <= k/4, f = 0
+//   once |a - b| >= k.  v < c needs min(a, b) < c + k/4, and an operand matters beyond being the minimum only within k
+//   of the other: the child visited FIRST gets c + 1.25 k.  The child visited second is cut by the first one's result
+//   a: exact (a below its cut) -> it matters only below a + k (at k = 0: only if it is <= a -- a tie goes to the
+//   right-hand operand -- so the cut is a, inflated); not exact -> it matters only as the minimum, below c + k/4.
+//   A clone hands its cut to its one child.
+// The nearer child is visited first, so the loose first-child cuts accumulate only along the path towards the nearest
+// primitives, which has to be walked anyway; everything off that path meets a cut formed from an exact value.
+// Cuts are inflated by 1e-5 relative wherever they are formed, which only makes them more permissive.
+__device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ nodes, uint32_t n, P4 p, const EvalStacks& S, bool live,
+                                                 float scene_T, float cut_root, uint32_t lane, float& out_d, uint32_t& out_id) {
+    S.pt[lane] = make_float4(p.x, p.y, p.z, p.w);
+    S.d[64u + lane] = make_float2(__builtin_inff(), __builtin_inff());
+    S.id[64u + lane] = make_uint2(SDF_NO_PRIM, SDF_NO_PRIM);
+    S.cut[64u + lane] = cut_root;
+    out_d = __builtin_inff();
+    out_id = SDF_NO_PRIM;
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+    if (lm == 0ull || n == 0u) return;
+    const int lead = (int)__builtin_ctzll(lm);
+    uint32_t i = 0;
+    bool second_visit = false;   // node i is the child that waited: its sibling's result is in the frame
+    for (;;) {
+        const GpuGenNode* __restrict__ N = nodes + i;
+        const uint32_t lv = N->level;
+        const float4 q4 = S.pt[(lv - 1u) * 64u + lane];
+        const float base = S.cut[lv * 64u + lane];
+        float cut = base;
+        if (second_visit) {
+            const float2 fr = S.d[lv * 64u + lane];
+            const float a = N->slot ? fr.x : fr.y, pk = N->parent_k;
+            cut = a < base ? __builtin_fminf(base, a + pk) : base - pk;
+            cut = cut + 1.0e-5f * (__builtin_fabsf(cut) + pk) + 1.0e-30f;
+        }
+        second_visit = false;
+        const bool want = live && !(gen_lower_bound(N, q4, scene_T) >= cut);
+        bool descended = false;
+        if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+            const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+            if (N->is_leaf) {
+                const float v = prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
+                float2 dd = S.d[lv * 64u + lane];
+                uint2 ii = S.id[lv * 64u + lane];
+                if (N->slot) { dd.y = v; ii.y = N->prim; } else { dd.x = v; ii.x = N->prim; }
+                S.d[lv * 64u + lane] = dd;
+                S.id[lv * 64u + lane] = ii;
+            } else {
+                const P4 c = down_point(N, r);
+                const float4 c4 = make_float4(c.x, c.y, c.z, c.w);
+                S.pt[lv * 64u + lane] = c4;
+                S.d[(lv + 1u) * 64u + lane] = make_float2(__builtin_inff(), __builtin_inff());   // faux_shader.rs:177
+                S.id[(lv + 1u) * 64u + lane] = make_uint2(SDF_NO_PRIM, SDF_NO_PRIM);
+                const float k = N->smooth_k;
+                const float cc = cut + 1.25f * k;
+                S.cut[(lv + 1u) * 64u + lane] = cc + 1.0e-5f * (__builtin_fabsf(cc) + k) + 1.0e-30f;
+                const uint32_t k0 = i + 1u;
+                if (k0 < N->skip_to) {
+                    const uint32_t k1 = nodes[k0].skip_to;
+                    uint32_t first = k0, second = REF_NONE;
+                    if (k1 < N->skip_to) {
+                        const float b0 = gen_lower_bound(nodes + k0, c4, scene_T), b1 = gen_lower_bound(nodes + k1, c4, scene_T);
+                        const uint32_t pick1 = (uint32_t)__builtin_amdgcn_readlane((int)((b1 < b0) ? 1u : 0u), lead);
+                        first = pick1 ? k1 : k0;
+                        second = pick1 ? k0 : k1;
+                    }
+                    S.ctl[lv] = second;
+                    i = first;
+                    descended = true;
+                }
+                // (an internal node with nothing live below it: its frame stays +inf and it is combined at once, below)
+            }
+        }
+        if (descended) continue;
+        // Node i is done (evaluated, or skipped: its slot keeps the +inf its frame was initialised with) -- unless it
+        // is an internal node that was visited and has just been found childless, which is combined like any parent.
+        bool combine_self = !N->is_leaf && __builtin_amdgcn_ballot_w64(want) != 0ull;
+        for (;;) {
+            uint32_t P;
+            if (combine_self) { P = i; combine_self = false; }
+            else {
+                P = nodes[i].parent;
+                if (P == REF_NONE) { out_d = S.d[64u + lane].x; out_id = S.id[64u + lane].x; return; }
+                const uint32_t lp = nodes[P].level;
+                const uint32_t j = S.ctl[lp];
+                if (j != REF_NONE) { S.ctl[lp] = REF_NONE; i = j; second_visit = true; break; }
+            }
+            // both children of P are done: uptree_dispatch (faux_shader.rs:84-94) into P's slot of its parent's frame
+            const GpuGenNode* __restrict__ A = nodes + P;
+            const uint32_t la = A->level;
+            const float2 c = S.d[(la + 1u) * 64u + lane];
+            const uint2 ci = S.id[(la + 1u) * 64u + lane];
+            float v;
+            uint32_t vi;
+            if (A->op == GEN_OP_CLONE) {
+                v = c.x;
+                vi = ci.x;
+            } else {
+                const bool left = c.x < c.y;
+                v = left ? c.x : c.y;
+                vi = left ? ci.x : ci.y;
+                const float k = A->smooth_k;
+                if (k > 0.f) {
+                    float t = k - __builtin_fabsf(c.x - c.y);
+                    t = t > 0.f ? t : 0.f;
+                    const float h = t / k;
+                    float q = h * h;
+                    q = q * k;
+                    q = q * 0.25f;
+                    v = v - q;
+                }
+            }
+            float2 dd = S.d[la * 64u + lane];
+            uint2 ii = S.id[la * 64u + lane];
+            if (A->slot) { dd.y = v; ii.y = vi; } else { dd.x = v; ii.x = vi; }
+            S.d[la * 64u + lane] = dd;
+            S.id[la * 64u + lane] = ii;
+            i = P;
+        }
+    }
 }
 
 template <int K>
 __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __restrict__ nodes, uint32_t n_nodes,
-                                                           uint32_t eval_levels, const float4* __restrict__ pts, uint32_t n,
+                                                           uint32_t eval_levels, uint32_t prune, float scene_T, uint32_t ctl_off,
+                                                           const float4* __restrict__ pts, const uint32_t* __restrict__ order, uint32_t n,
                                                            uint32_t k, float* __restrict__ out_dist,
                                                            uint32_t* __restrict__ out_prim) {
     extern __shared__ float4 gstk[];
+    uint32_t* const ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(gstk) + ctl_off);
     const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * 64u + lane;
-    const bool alive = i < n;
+    const uint32_t slot = blockIdx.x * 64u + lane;
+    const bool alive = slot < n;
+    const uint32_t i = alive ? (order ? order[slot] : slot) : 0u;   // results go back to the caller's index
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
     if (alive) p = pts[i];
     const bool in_dom = in_domain3(p.x, p.y, p.z);   // see in_domain3: (NaN, SDF_NO_PRIM) otherwise, as on the pruned path
@@ -1667,7 +1918,15 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
         if (eval_levels) {   // a combine that is not a plain minimum is in effect: the real post-order evaluation
             float d;
             uint32_t id;
-            walk_eval(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, eval_stacks(gstk, eval_levels), lane, d, id);
+            EvalStacks S = eval_stacks(gstk, eval_levels);
+            S.ctl = ctl;
+            if (prune) {
+                const bool live = alive && in_dom;
+                const float U = gen_seed_value(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, live, scene_T, S.pt, lane);
+                walk_eval_pruned(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, S, live, scene_T, U + 1.0e-5f * __builtin_fabsf(U) + 1.0e-30f, lane, d, id);
+            } else {
+                walk_eval(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, S, lane, d, id);
+            }
             if (alive) {
                 out_dist[i] = in_dom ? d : __builtin_nanf("");
                 if (out_prim) out_prim[i] = in_dom ? id : SDF_NO_PRIM;
@@ -1675,7 +1934,15 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
             return;
         }
         AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
-        walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (prune) {
+            // the value of one nearby primitive as the first radius (that primitive is met again in the walk and takes
+            // the slot then: an index of SDF_NO_PRIM loses every tie)
+            const bool live = alive && in_dom;
+            acc.best = gen_seed_value(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, live, scene_T, gstk, lane);
+            walk_general_pruned(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, false, live, scene_T, acc, gstk, ctl, lane);
+        } else {
+            walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        }
         if (alive) {
             out_dist[i] = in_dom ? acc.best : __builtin_nanf("");
             if (out_prim) out_prim[i] = in_dom ? acc.bid : SDF_NO_PRIM;
@@ -1683,7 +1950,8 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
     } else {
         AccK<K> acc;
         acc.init();
-        walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
+        if (prune) walk_general_pruned(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, false, alive && in_dom, scene_T, acc, gstk, ctl, lane);
+        else walk_general(nodes, n_nodes, P4{p.x, p.y, p.z, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (!in_dom) acc.init_nan();
         if (alive) {
 #pragma unroll
@@ -1697,12 +1965,14 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
 }
 
 __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __restrict__ nodes, uint32_t n_nodes,
-                                                            uint32_t eval_levels, sdfgpu_camera cam, uint32_t width, uint32_t height,
+                                                            uint32_t eval_levels, uint32_t prune, float scene_T, uint32_t ctl_off,
+                                                            sdfgpu_camera cam, uint32_t width, uint32_t height,
                                                             sdfgpu_march_params mp, uint32_t tile_first, uint32_t tile_stride,
                                                             uint32_t tile_count, uint32_t row_major,
                                                             uint8_t* __restrict__ o_hit, float* __restrict__ o_depth,
                                                             float* __restrict__ o_normal, uint32_t* __restrict__ o_prim) {
     extern __shared__ float4 gstk[];
+    uint32_t* const ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(gstk) + ctl_off);
     const uint32_t lane = threadIdx.x;
     const uint32_t tile_local = blockIdx.x;
     if (tile_local >= tile_count) return;
@@ -1726,7 +1996,18 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         if (alive) { px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t; }
         AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
-        if (eval_levels) walk_eval(nodes, n_nodes, P4{px, py, pz, 1.0f}, eval_stacks(gstk, eval_levels), lane, acc.best, acc.bid);
+        if (prune) {
+            const float U = gen_seed_value(nodes, n_nodes, P4{px, py, pz, 1.0f}, alive, scene_T, gstk, lane);
+            if (eval_levels) {
+                EvalStacks S = eval_stacks(gstk, eval_levels);
+                S.ctl = ctl;
+                walk_eval_pruned(nodes, n_nodes, P4{px, py, pz, 1.0f}, S, alive, scene_T, U + 1.0e-5f * __builtin_fabsf(U) + 1.0e-30f, lane,
+                                 acc.best, acc.bid);
+            } else {
+                acc.best = U;
+                walk_general_pruned(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, false, alive, scene_T, acc, gstk, ctl, lane);
+            }
+        } else if (eval_levels) walk_eval(nodes, n_nodes, P4{px, py, pz, 1.0f}, eval_stacks(gstk, eval_levels), lane, acc.best, acc.bid);
         else walk_general(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
             if (acc.best < mp.eps_hit) { hit = true; hit_prim = acc.bid; alive = false; }
@@ -1741,8 +2022,12 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             AccNearest acc{__builtin_inff(), SDF_NO_PRIM};
-            walk_general(nodes, n_nodes, P4{px + sgn[j][0] * h, py + sgn[j][1] * h, pz + sgn[j][2] * h, 1.0f},
-                         hit ? hit_prim : 0xFFFFFFFEu, acc, gstk, lane);
+            if (prune)
+                walk_general_pruned(nodes, n_nodes, P4{px + sgn[j][0] * h, py + sgn[j][1] * h, pz + sgn[j][2] * h, 1.0f},
+                                    hit ? hit_prim : SDF_NO_PRIM, true, hit, scene_T, acc, gstk, ctl, lane);
+            else
+                walk_general(nodes, n_nodes, P4{px + sgn[j][0] * h, py + sgn[j][1] * h, pz + sgn[j][2] * h, 1.0f},
+                             hit ? hit_prim : 0xFFFFFFFEu, acc, gstk, lane);
             f[j] = acc.best;
         }
         if (hit) {
@@ -1873,11 +2158,12 @@ static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const 
 // LDS of the general path: one float4 per level per lane; with the post-order combine, also the two
 // results (distance, index) of every level.
 static uint32_t general_eval_levels(const DeviceTree& d) { return d.gen_eval ? d.stack_depth : 0u; }
-static size_t general_lds(const DeviceTree& d) {
+static size_t general_ctl_off(const DeviceTree& d) {   // where the pruned walks' control stack starts: behind everything else
     size_t b = (size_t)(d.stack_depth + 1u) * 64u * sizeof(float4);
-    if (d.gen_eval) b += (size_t)(d.stack_depth + 2u) * 64u * (sizeof(float2) + sizeof(uint2));
+    if (d.gen_eval) b += (size_t)(d.stack_depth + 2u) * 64u * (sizeof(float2) + sizeof(uint2) + sizeof(float));
     return b;
 }
+static size_t general_lds(const DeviceTree& d) { return general_ctl_off(d) + 64u * sizeof(uint32_t); }
 
 hipError_t launch_box_bounds(const SdfBoundingBoxBlock* d_box, const float* d_pts, uint32_t n, float* d_min, float* d_max,
                              hipStream_t s) {
@@ -1890,8 +2176,8 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t*
                           uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s, bool stats_asm_walk) {
     if (d.gen) {   // general path: exhaustive literal chain (no counters, no reordering needed)
         if (n == 0) return hipSuccess;
-        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d),
-                                                                                       (const float4*)pts, n, 1, out_dist, out_prim);
+        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), d.gen_prune ? 1u : 0u,
+                                                                                       d.margin_T, (uint32_t)general_ctl_off(d), (const float4*)pts, order, n, 1, out_dist, out_prim);
         return hipGetLastError();
     }
     if (st) return stats_asm_walk ? launch_nearest_t<2>(d, pts, order, n, out_dist, out_prim, st, s)
@@ -1922,10 +2208,10 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
         dim3 grid((n + 63u) / 64u), block(64);
         const size_t lds = general_lds(d);
         const float4* p4 = (const float4*)pts;
-        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
-        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
-        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
-        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, p4, n, k, out_dist, out_prim);
+        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
         return hipGetLastError();
     }
     if (d.chain) {
@@ -2006,7 +2292,7 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s) {
     if (tile_count == 0) return hipSuccess;
     if (d.gen) {
-        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), cam, w, h, mp, tile_first,
+        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), cam, w, h, mp, tile_first,
                                                                                 tile_stride, tile_count, row_major ? 1u : 0u,
                                                                                 hit, depth, normal, prim);
         return hipGetLastError();

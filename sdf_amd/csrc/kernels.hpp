@@ -65,6 +65,7 @@ struct DeviceTree {
     GpuGenNode* gen = nullptr;          // general path: all nodes, pre-order
     uint32_t n_gen = 0;
     bool gen_eval = false;              // general path runs the post-order combine (smooth union in effect)
+    bool gen_prune = false;             // general path: nodes carry boxes, the walks skip subtrees (gpu_tree.hpp GpuGenNode)
     uint32_t root_ref = REF_NONE;
     uint32_t n_leaf = 0;
     uint32_t stack_depth = 1;
