@@ -24,19 +24,34 @@ def run(seed, iters, gpu=None, log=print, heavy=False):
       # the chain path where every map is an isometry, the exhaustive general path otherwise
       pca = heavy and rng.random() < 0.33
       popts = {"pca_trans_inverse": True} if pca else None
+      # heavy: a fifth of the other scenes with the opt-in extensions in effect (smooth unions with a radius from far
+      # below to far above the primitives' spacing, box frames, one lattice clone): the general path, whose walks
+      # prune from 256 resident nodes on (kernels.hip walk_eval_pruned / walk_general_pruned)
+      ext = 0
+      smooth_k = 0.0
+      if heavy and not pca and rng.random() < 0.2:
+          ext = int(rng.choice([S.EXT_SMOOTH_UNION, S.EXT_BOX_FRAME, S.EXT_CLONE_REPAIR, S.EXT_SMOOTH_UNION | S.EXT_BOX_FRAME | S.EXT_CLONE_REPAIR]))
+          if ext & S.EXT_SMOOTH_UNION:
+              smooth_k = scale * float(rng.choice([0.02, 0.5, 2.0, 30.0]))
       parts = []
       for k in range(n):
           size = scale * float(rng.choice([1e-3, 0.05, 1.0])) * rng.uniform(0.5, 2.0)
           e = S.SdfSphere(size) if rng.random() < 0.5 else S.SdfBox(tuple(float(v) for v in size * rng.uniform(0.2, 2.0, 3)))
+          if (ext & S.EXT_BOX_FRAME) and (k == 0 or rng.random() < 0.25):
+              e = S.SdfBoxFrame(tuple(float(v) for v in size * rng.uniform(0.5, 2.0, 3)), float(0.1 * size))
           pos = offset + scale * 20 * rng.uniform(-1, 1, 3) if (k == 0 or rng.random() > 0.15) else last_pos   # 15% exact duplicates of a position
           last_pos = pos
           q = S.Quat.from_euler_xyz(*(float(v) for v in rng.uniform(0, 6.28, 3)))
           t = S.Transform.from_translation(tuple(float(v) for v in pos))
           t.rotation = q
-          parts.append(S.SdfBuilder.primitive(e, opts=popts).transform(t))
+          leaf = S.SdfBuilder.primitive(e, opts=popts).transform(t)
+          if (ext & S.EXT_CLONE_REPAIR) and k == n // 2:
+              d = tuple(float(v) for v in scale * rng.uniform(2.0, 8.0, 3))
+              leaf = S.SdfBuilder.primitive(e).operation(S.SdfCaaClone(d, (-1, -2, 0), (2, 1, 1)))
+          parts.append(leaf)
       b = parts[0]
       if n > 1:
-          b = b.operation(S.SdfUnion(0.0))
+          b = b.operation(S.SdfUnion(smooth_k))
           for x in parts[1:]:
               b = b.with_(x)
       buf = b.finalize().expanded().make_buffer()
@@ -49,11 +64,12 @@ def run(seed, iters, gpu=None, log=print, heavy=False):
           u /= np.linalg.norm(u, axis=1, keepdims=True)
           pts[-150:, :3] = (offset + u * scale * 20 * rng.choice([20.0, 300.0, 3e4], size=(150, 1))).astype(np.float32)
       pts[: min(n, 50), :3] = [buf.downtree_buffer[i]["bounding_box"]["matrix"][12:15] for i in np.flatnonzero(buf.downtree_buffer["is_primitive"])[: min(n, 50)]]  # primitive centres
-      d0, i0 = O.nearest(buf, pts, mode=O.MODE_EXHAUSTIVE, threads=8)
       k = int(rng.choice([1, 3, 8, 16]))
-      dk0, ik0 = O.knn(buf, pts[:800], k, threads=8)
-      for mode in ((S.BOUNDS_AUTO, S.BOUNDS_NONE) if pca else (S.BOUNDS_BVH, S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE)):
-          gpu.upload_tree(buf, bounds=mode)
+      with O.extensions(ext):
+          d0, i0 = O.nearest(buf, pts, mode=O.MODE_EXHAUSTIVE, threads=8)
+          dk0, ik0 = O.knn(buf, pts[:800], k, threads=8)
+      for mode in ((S.BOUNDS_AUTO,) if ext else (S.BOUNDS_AUTO, S.BOUNDS_NONE) if pca else (S.BOUNDS_BVH, S.BOUNDS_AABB, S.BOUNDS_OBB, S.BOUNDS_NONE)):
+          gpu.upload_tree(buf, bounds=mode, extensions=ext)
           d, i = gpu.nearest(pts)
           if not (np.array_equal(bits(d), bits(d0)) and np.array_equal(i, i0)):
               j = int(np.flatnonzero((bits(d) != bits(d0)) | (i != i0))[0])
@@ -75,9 +91,10 @@ def run(seed, iters, gpu=None, log=print, heavy=False):
               t_min = float(rng.choice([0.0, 0.0, 0.5 * L]))
           cam = S.camera_look_at(tuple(float(v) for v in offset + eye), tuple(float(v) for v in offset), (0, 1, 0), 0.8, w, h)
           mp = S.march_params(max_steps=steps, eps_hit=1e-3 * scale, t_min=t_min, t_max=8 * L, normal_h=1e-3 * scale)
-          ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
-          for mode in ((S.BOUNDS_AUTO,) if pca else (S.BOUNDS_BVH, S.BOUNDS_OBB)):
-              gpu.upload_tree(buf, bounds=mode)
+          with O.extensions(ext):
+              ref = O.render(buf, cam, w, h, mp, mode=O.MODE_EXHAUSTIVE, threads=8)
+          for mode in ((S.BOUNDS_AUTO,) if (pca or ext) else (S.BOUNDS_BVH, S.BOUNDS_OBB)):
+              gpu.upload_tree(buf, bounds=mode, extensions=ext)
               img = gpu.render(cam, w, h, mp)
               ok = all(np.array_equal(img[q], ref[q]) for q in ("hit", "prim")) and np.array_equal(bits(img["depth"]), bits(ref["depth"])) and np.array_equal(bits(img["normal"]), bits(ref["normal"]))
               if not ok:
