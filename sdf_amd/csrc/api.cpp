@@ -421,7 +421,8 @@ int build_grid(sdfgpu_ctx* c, const CompactTree& t) {
     c->info.grid_cells = 0;
     if (!env_on || !c->candidate_grid) return SDFGPU_OK;
     const uint32_t b = t.info.bounds;
-    if (!t.gen.empty() || (b != SDFGPU_BOUNDS_AABB && b != SDFGPU_BOUNDS_BVH) || t.leaves.size() < GRID_MIN_PRIMS) return SDFGPU_OK;
+    // (every pruned mode: what a list proves is about the primitives, whichever boxes the walk that built it used)
+    if (!t.gen.empty() || (b != SDFGPU_BOUNDS_AABB && b != SDFGPU_BOUNDS_BVH && b != SDFGPU_BOUNDS_OBB) || t.leaves.size() < GRID_MIN_PRIMS) return SDFGPU_OK;
     if (!(t.lipschitz < 1.001f)) return SDFGPU_OK;   // rigid leaves only (what the pruned modes accept anyway)
     float ext[3], maxext = 0.f;
     for (int a = 0; a < 3; ++a) {

@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void knn_kernel(TreeView T, const float4* __re
     // so the result is the same and the first descents no longer wander through subtrees a converged radius would
     // have skipped (caller-sorted k = 8 batch 1.126 -> 0.98 ms with lip r for |p - c|; the exact final radius as the cap
     // would give 0.90).
-    if constexpr (MODE != SDFGPU_BOUNDS_OBB) {
+    {
         if (T.gblock != nullptr) {
             const f32x16 G = load_rec64_s48(T.gblock, 0u);
             const float gx = __builtin_fminf(__builtin_fmaxf((p.x - G[0]) * G[3], -1.f), 65536.f);
@@ -1036,7 +1036,6 @@ __global__ __launch_bounds__(64) void eye_walk_kernel(TreeView T, float ex, floa
 template <int MODE, bool COUNT, bool CHAIN>
 __device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py, float pz, float mg, bool active, uint32_t lane,
                                           float& best, uint32_t& bid, float& budget, bool& adv, WaveCounters& wc) {
-    if constexpr (MODE == SDFGPU_BOUNDS_OBB) return false;
     if (T.gblock == nullptr) return false;
     const f32x16 G = load_rec64_s48(T.gblock, 0u);   // GridBlock: lo[3], inv_cell[3], n[3], n[0]/4, n[1]/4, bricks_off
     // cell of the point: floor((p - lo) / cell) per axis, out-of-range and non-numbers fail the unsigned compare
