@@ -286,8 +286,8 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
             torch.cuda.synchronize()
             kms.append(e0.elapsed_time(e1))
         call_ms = float(np.mean(kms))
-        tr, trn = profiled_traffic("knn_kernel<1, 8")
-        out["roofline"] = roofline_object(st, call_ms, "sdfgpu::knn_kernel<1, 8, false>", n * 16 + n * k * 8 + int(info.device_bytes),
+        tr, trn = profiled_traffic("knn_kernel<1, 8, false")
+        out["roofline"] = roofline_object(st, call_ms, "sdfgpu::knn_kernel<1, 8, false, false>", n * 16 + n * k * 8 + int(info.device_bytes),
                                           note="kernel_ms_avg = the whole sdfgpu_knn_dev call (curve keys + radix sort + walk) under HIP "
                                                "events, so the kernel's own rate is higher (profiles/ has its rocprofv3 duration); fp32 "
                                                "VALU-bound walk, K-slot insertion counted as 2 flops per offered primitive",
@@ -323,7 +323,7 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
     return out
 
 
-def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true, false>"):
+def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true, false"):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE are collected in separate runs by tools/profile_bench.sh;
     bench.py itself cannot read counters).  FETCH_SIZE/WRITE_SIZE are in KiB; the reads of
@@ -339,7 +339,8 @@ def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true, false>"):
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            # exactly this instantiation (profiles of different rounds name it with or without the trailing CHAIN = false)
+            if (k.endswith(kernel_substr + ">") or k.endswith(kernel_substr + ", false>")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 best = (path, (v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0)
     if best is None:
         return None, "no PMC profile committed"
@@ -491,16 +492,19 @@ def variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev):
     for cfg in (2, 3, 4):
         wlx = W.CONFIGS[cfg]
         node = S.random_scene(wlx.n_prims, wlx.seed)
-        t0 = time.perf_counter()
-        b = node.expanded().make_buffer()
-        fl = (time.perf_counter() - t0) * 1e3
-        g3 = S.SdfGpu(dev.index)
-        t0 = time.perf_counter()
-        g3.upload_tree(b)
-        torch.cuda.synchronize()
-        upx = (time.perf_counter() - t0) * 1e3
-        g3.close()
-        out["upload_ms"][f"{wlx.n_prims}_prims"] = {"flatten_expanded_make_buffer_ms": fl, "sdfgpu_upload_tree_ms": upx}
+        fl, upx = [], []
+        for _ in range(2):   # the better of two: the first upload of a process also loads the grid build's code objects
+            t0 = time.perf_counter()
+            b = node.expanded().make_buffer()
+            fl.append((time.perf_counter() - t0) * 1e3)
+            g3 = S.SdfGpu(dev.index)
+            t0 = time.perf_counter()
+            g3.upload_tree(b)
+            torch.cuda.synchronize()
+            upx.append((time.perf_counter() - t0) * 1e3)
+            g3.close()
+        out["upload_ms"][f"{wlx.n_prims}_prims"] = {"flatten_expanded_make_buffer_ms": min(fl), "sdfgpu_upload_tree_ms": min(upx),
+                                                    "note": "better of two runs; upload = validate + SAH build + candidate grid + copies"}
     return out
 
 
@@ -804,7 +808,7 @@ def main():
             bytes_alg = npix * 21 + int(info.device_bytes)
             traffic, traffic_note = profiled_traffic()
             line["roofline"] = roofline_object(
-                st, k_avg, "sdfgpu::render_pass_kernel<1, false, true, false>", bytes_alg,
+                st, k_avg, "sdfgpu::render_pass_kernel<1, false, true, false, false>", bytes_alg,
                 note="fp32 VALU-bound tree walk, no dense contraction (no MFMA); kernel_ms_avg = isolated launches under "
                      "HIP events on the launch stream, outside the timed region",
                 traffic=traffic, traffic_note=traffic_note)
