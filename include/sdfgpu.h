@@ -80,7 +80,20 @@ typedef struct sdfgpu_tree_info {
     float scene_hi[3];
     uint32_t extensions;     /* sdfgpu_extension bits that are in effect in this tree (0 = evaluated as the crate is written) */
     uint32_t grid_cells;     /* cells of the nearest-candidate grid built for the march (0 = none); its bytes are part of device_bytes */
+    uint32_t walk;           /* sdfgpu_walk: which resident form serves this tree's queries */
+    uint32_t reserved;
 } sdfgpu_tree_info;
+
+/* How a tree is walked (sdfgpu_tree_info.walk).  Results do not depend on it; cost does. */
+typedef enum sdfgpu_walk {
+    SDFGPU_WALK_HIERARCHY = 0,          /* pruned walk over a box hierarchy (`bounds` says whose), or every primitive (NONE) */
+    SDFGPU_WALK_CHAIN = 1,              /* the same over the library's hierarchy, leaf values through the per-level point chain
+                                           (buffers whose internal nodes re-base the point with rigid maps: the crate's own) */
+    SDFGPU_WALK_GENERAL_PRUNED = 2,     /* the buffer's topology with the post-order combine (extensions in effect, or as below
+                                           but rigid), subtrees skipped on library-derived boxes */
+    SDFGPU_WALK_GENERAL_EXHAUSTIVE = 3  /* the same without skipping: non-rigid or projective maps, small trees, or smooth radii
+                                           of the order of the scene -- O(nodes) per query */
+} sdfgpu_walk;
 
 /* Pinhole camera as plain data.  Ray through pixel (x, y):
  *   pw  = (origin + du * x) + dv * y        (per component, each op rounded)

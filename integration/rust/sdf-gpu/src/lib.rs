@@ -67,6 +67,9 @@ pub struct TreeInfo {
     pub extensions: u32,
     /// cells of the nearest-candidate grid built for the march (0 = none)
     pub grid_cells: u32,
+    /// sdfgpu_walk: 0 hierarchy, 1 chain, 2 general pruned, 3 general exhaustive
+    pub walk: u32,
+    pub reserved: u32,
 }
 
 pub const LAYOUT_GLAM_SSE2: u32 = 0;

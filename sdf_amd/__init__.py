@@ -8,6 +8,7 @@ loudly if it has not been built.
 from . import _ffi
 from ._ffi import (BOUNDS_AABB, BOUNDS_AUTO, BOUNDS_BVH, BOUNDS_NONE, BOUNDS_OBB, EXT_BOX_FRAME,
                    EXT_CLONE_REPAIR, EXT_SMOOTH_UNION, NO_PRIM,
+                   WALK_CHAIN, WALK_GENERAL_EXHAUSTIVE, WALK_GENERAL_PRUNED, WALK_HIERARCHY,
                    Camera, MarchParams, load_library)
 from .gpu import (SdfComm, SdfGpu, SdfGpuError, camera_look_at, compact_host, knn_sharded, march_params, nearest_sharded,
                   query_slice)

@@ -51,6 +51,7 @@ NO_PRIM = 0xFFFFFFFF
 BOUNDS_AUTO, BOUNDS_AABB, BOUNDS_OBB, BOUNDS_NONE, BOUNDS_BVH = 0, 1, 2, 3, 4
 LAYOUT_GLAM_SSE2 = 0
 EXT_SMOOTH_UNION, EXT_BOX_FRAME, EXT_CLONE_REPAIR = 1, 2, 4
+WALK_HIERARCHY, WALK_CHAIN, WALK_GENERAL_PRUNED, WALK_GENERAL_EXHAUSTIVE = 0, 1, 2, 3
 
 OK = 0
 ERR_INVALID_ARG, ERR_HIP, ERR_NO_TREE, ERR_LAYOUT, ERR_BAD_TREE = -1, -2, -3, -4, -5
@@ -76,6 +77,8 @@ class TreeInfo(C.Structure):
         ("scene_hi", C.c_float * 3),
         ("extensions", C.c_uint32),
         ("grid_cells", C.c_uint32),
+        ("walk", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -903,6 +903,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
         gi.n_inner = n_inner;
         gi.max_level = max_level;
         gi.bounds = SDFGPU_BOUNDS_NONE;
+        gi.walk = out->gen_prune ? SDFGPU_WALK_GENERAL_PRUNED : SDFGPU_WALK_GENERAL_EXHAUSTIVE;
         gi.identity_inner = identity_inner ? 1 : 0;
         gi.rigid_leaves = rigid ? 1 : 0;
         gi.device_bytes = out->gen.size() * sizeof(GpuGenNode);
@@ -1071,6 +1072,7 @@ int compact_tree(const SdfOperationBlock* dt, const SdfOperationUptreeBlock* ut,
     info.max_level = max_level;
     info.stack_depth = out->stack_depth;
     info.bounds = mode;
+    info.walk = chain ? SDFGPU_WALK_CHAIN : SDFGPU_WALK_HIERARCHY;
     info.identity_inner = identity_inner ? 1 : 0;
     info.rigid_leaves = rigid ? 1 : 0;
     info.device_bytes = out->leaves.size() * sizeof(GpuLeaf) + out->inner.size() * sizeof(GpuInner) +

@@ -69,6 +69,22 @@ def test_default_is_as_written():
     assert rc == _ffi.ERR_INVALID_ARG
 
 
+def test_which_walk_serves_a_tree():
+    # sdfgpu_tree_info.walk: small trees under an extension walk exhaustively, from 256 resident nodes on they prune,
+    # unless the smooth radius is of the order of the scene; plain buffers take the hierarchy, the crate's literal
+    # buffers (PCA trans_inverse in the merged boxes) the chain path
+    rc, info, _ = S.compact_host(smooth_scene(), extensions=S.EXT_SMOOTH_UNION)
+    assert rc == 0 and info.walk == S.WALK_GENERAL_EXHAUSTIVE
+    rc, info, _ = S.compact_host(smooth_scene(k=0.3, n=200), extensions=S.EXT_SMOOTH_UNION)
+    assert rc == 0 and info.walk == S.WALK_GENERAL_PRUNED
+    rc, info, _ = S.compact_host(smooth_scene(k=40.0, n=200), extensions=S.EXT_SMOOTH_UNION)
+    assert rc == 0 and info.walk == S.WALK_GENERAL_EXHAUSTIVE
+    rc, info, _ = S.compact_host(smooth_scene(k=0.3, n=200))
+    assert rc == 0 and info.walk == S.WALK_HIERARCHY and info.bounds == S.BOUNDS_BVH
+    rc, info, _ = S.compact_host(S.random_scene_buffer(300, 5, opts={"pca_trans_inverse": True}))
+    assert rc == 0 and info.walk == S.WALK_CHAIN
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 def test_two_restatements_agree_on_extensions(name):
     make, ext, extent = SCENES[name]
