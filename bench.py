@@ -484,6 +484,51 @@ def variants(a, gpu, cam, mp, w, h, slots, depth, wl, dev):
                            "note": f"{wl.name} built with pca_trans_inverse (the crate's literal merged boxes): chain path, {depth} frames in "
                                    "flight; before round 3 such a buffer was walked exhaustively, O(nodes) per query"}
     gc.close()
+    # The headline scene with every union's smooth radius set (elements.rs:207-211) and the SMOOTH_UNION extension on:
+    # the general path (post-order combine over the buffer's own topology), whose walks prune since round 3
+    # (walk_eval_pruned: cuts).  Its march has none of the pruned path's machinery, so the frame is half the
+    # headline's size each way; the exhaustive walk of the same tree (SDFGPU_GEN_PRUNE=0) is timed beside it on a small frame.
+    buf_h = W.scene(wl)
+    sm = S.SdfTreeBuffer(buf_h.downtree_buffer, buf_h.uptree_buffer.copy())
+    dtb = sm.downtree_buffer
+    idx = np.arange(len(dtb), dtype=np.int64)
+    post = idx + dtb["len"].astype(np.int64) - (dtb["level"].astype(np.int64) - 1)   # post-order position of pre-order node i
+    unions = (dtb["is_primitive"] == 0) & (dtb["op_code"] == 0)
+    k_smooth = 1.0
+    fl = sm.uptree_buffer["op_specific"]["floats"]
+    fl[post[unions], 0] = k_smooth
+    res = {}
+    for tag, env, div in (("pruned_small", None, 8), ("exhaustive_small", "0", 8), ("pruned", None, 2)):
+        ws, hs = max(8, w // div), max(8, h // div)
+        cams = W.camera(wl, ws, hs)
+        os_ = (torch.empty(ws * hs, dtype=torch.uint8, device=dev), torch.empty(ws * hs, dtype=torch.float32, device=dev),
+               torch.empty(ws * hs * 3, dtype=torch.float32, device=dev), torch.empty(ws * hs, dtype=torch.int32, device=dev))
+        if env is None:
+            os.environ.pop("SDFGPU_GEN_PRUNE", None)
+        else:
+            os.environ["SDFGPU_GEN_PRUNE"] = env
+        gs = S.SdfGpu(dev.index)
+        infs = gs.upload_tree(sm, extensions=S.EXT_SMOOTH_UNION)
+        st_ = torch.cuda.current_stream().cuda_stream
+
+        def sframe(kk):
+            gs.render_dev(cams, ws, hs, mp, os_[0].data_ptr(), os_[1].data_ptr(), os_[2].data_ptr(), os_[3].data_ptr(), st_)
+
+        sframe(0)
+        mss = run(sframe, 1 if env is not None else 2)
+        res[tag] = (mss, int(infs.walk), int(os_[0].sum().item()), ws, hs)
+        gs.close()
+        del os_
+    os.environ.pop("SDFGPU_GEN_PRUNE", None)
+    pr, ps, ex = res["pruned"], res["pruned_small"], res["exhaustive_small"]
+    out["smooth_union"] = {"value": pr[3] * pr[4] / pr[0] / 1e3, "ms_per_step": pr[0], "unit": "Mrays/s",
+                           "width": pr[3], "height": pr[4], "smooth_radius": k_smooth, "walk": pr[1],
+                           "small_frame": {"width": ps[3], "height": ps[4], "pruned_ms": ps[0], "exhaustive_ms": ex[0],
+                                           "speedup_over_exhaustive": ex[0] / ps[0], "same_hit_count": ps[2] == ex[2]},
+                           "note": f"{wl.name} with smooth radius {k_smooth} on every union, SDFGPU_EXT_SMOOTH_UNION: general path, pruned by cuts "
+                                   "(walk 2 = SDFGPU_WALK_GENERAL_PRUNED), one frame in flight, half the headline's size each way; the "
+                                   "exhaustive walk of the same tree is timed on a frame an eighth of the size each way (506 wavefronts: "
+                                   "neither fills the GPU there)"}
     for kk in range(2 * depth):   # slots back to the headline scene's frame
         frame(gpu, cam, slots[kk % depth])
     torch.cuda.synchronize()
