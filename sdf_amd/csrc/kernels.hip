@@ -355,6 +355,31 @@ __device__ __forceinline__ float leaf_value(const TreeView& T, uint32_t id, cons
     }
 }
 
+// The same value for a per-lane primitive (the march's seed on the chain path): every lane fetches its own chain's
+// records with vector loads -- lanes with the same seed read the same lines -- and applies them in the reference's
+// order, one rounded mat-vec per level.  The wavefront loops to the longest chain among its lanes; a lane whose chain
+// has ended keeps its point.  first / cnt: the lane's {first record, count} (TreeView::chain, per primitive).
+__device__ __forceinline__ float leaf_value_lane_chain(const TreeView& T, uint32_t id, uint32_t first, uint32_t cnt, bool on,
+                                                       float px, float py, float pz) {
+    // (the records' offset is folded into the lane's own 32-bit offset from T.chain: a second base pointer would cost
+    // the march kernel an SGPR pair it does not have)
+    const uint32_t off0 = ((T.n_leaf * 8u + 63u) & ~63u) + (first << 6);
+    float x = px, y = py, z = pz;
+    const uint32_t n = on ? cnt : 0u;
+    const uint32_t n_max = __builtin_amdgcn_readfirstlane(__ockl_wfred_max_u32(n));
+    for (uint32_t j = 0; j < n_max; ++j) {
+        if (j < n) {
+            const float4* __restrict__ q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T.chain) + (off0 + (j << 6)));
+            const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+            const float nx = ((r0.x * x + r0.y * y) + r0.z * z) + r0.w;
+            const float ny = ((r1.x * x + r1.y * y) + r1.z * z) + r1.w;
+            const float nz = ((r2.x * x + r2.y * y) + r2.z * z) + r2.w;
+            x = nx; y = ny; z = nz;
+        }
+    }
+    return on ? leaf_eval(T.leaf + id, x, y, z) : __builtin_inff();
+}
+
 // Wave-uniform branch-and-prune walk.  On return the accumulator holds the
 // result over every primitive of the tree for each lane whose bit is set in
 // `drive` (other lanes ride along: they see every value the wave evaluates).
@@ -1214,7 +1239,10 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         const float4* __restrict__ q = reinterpret_cast<const float4*>(T.leaf + last);
         c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
     }
-    const f32x16 no_rec{};   // CHAIN: leaf_value fetches its records itself
+    if (CHAIN && alive && last != SDF_NO_PRIM) {   // chain path: the seed's {first record, count} instead
+        const float2 fc = reinterpret_cast<const float2*>(T.chain)[last];
+        c0.x = fc.x; c0.y = fc.y;
+    }
     // FIRST pass with the eye's walk at hand: taken instead of this wavefront's own first walk when every
     // marching lane really stands at the eye (a degenerate ray direction would put a lane elsewhere)
     bool eye_step = false;
@@ -1234,20 +1262,13 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
         const bool seeded = last != SDF_NO_PRIM;
         float seed;
         if constexpr (CHAIN) {
-            // A seed's value goes through its whole chain, whose records cannot be kept per lane: the distinct seeds of
-            // the marching lanes (one to three in a tile's wavefront) are evaluated one after the other, wave-uniformly
-            // like a visited leaf; every lane keeps the value of its own.
-            seed = __builtin_inff();
-            uint32_t lw = (active & seeded) ? last : SDF_NO_PRIM;
-            unsigned long long todo = __builtin_amdgcn_ballot_w64(lw != SDF_NO_PRIM);
-            while (todo != 0ull) {
-                const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)__builtin_ctzll(todo));
-                const float v = leaf_value<true>(T, sid, no_rec, px, py, pz);
-                const bool same = lw == sid;
-                seed = same ? v : seed;
-                lw = same ? SDF_NO_PRIM : lw;
-                todo = __builtin_amdgcn_ballot_w64(lw != SDF_NO_PRIM);
-            }
+            // A seed's value goes through its whole chain, whose records cannot be kept in registers as a plain leaf's
+            // are: every lane walks its own seed's chain with vector loads (leaf_value_lane_chain; c0.x / c0.y keep the
+            // lane's {first record, count}).  (First version: the distinct seeds of the marching lanes one after the
+            // other, wave-uniformly with scalar loads -- two or three whole chains per iteration instead of one: the
+            // crate-buffer frame 3.59 -> 2.18 ms isolated.  The list pass stays wave-uniform: every lane evaluating its
+            // own list through vector loads measured 4.6 ms -- there the lanes' candidates differ and so do their lines.)
+            seed = leaf_value_lane_chain(T, last, __builtin_bit_cast(uint32_t, c0.x), __builtin_bit_cast(uint32_t, c0.y), active & seeded, px, py, pz);
         } else {
             const float lx = ((c0.x * px + c0.y * py) + c0.z * pz) + c0.w;
             const float ly = ((c1.x * px + c1.y * py) + c1.z * pz) + c1.w;
@@ -1324,6 +1345,12 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
                 c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3];
             }
         }
+        if (CHAIN && !cheap) {
+            if ((state == 0u) & (s < pa.step_end) & (last != SDF_NO_PRIM)) {
+                const float2 fc = reinterpret_cast<const float2*>(T.chain)[last];
+                c0.x = fc.x; c0.y = fc.y;
+            }
+        }
     }
     const uint32_t steps = s - pa.step_begin;
     const bool hit = state == 1u;
@@ -1339,21 +1366,17 @@ __global__ __launch_bounds__(256) void render_pass_kernel(TreeView T, sdfgpu_cam
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
     float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
-    if constexpr (CHAIN) {   // the taps of every distinct hit primitive, wave-uniformly (as the seeds above)
+    if constexpr (CHAIN) {   // the four taps through the hit primitive's chain, per lane (as the seeds above)
         const float h = mp.normal_h;
-        uint32_t hw = hit ? hit_prim : SDF_NO_PRIM;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(hw != SDF_NO_PRIM);
-        while (todo != 0ull) {
-            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)hw, (int)__builtin_ctzll(todo));
-            const float v0 = leaf_value<true>(T, sid, no_rec, px + h, py - h, pz - h);
-            const float v1 = leaf_value<true>(T, sid, no_rec, px - h, py - h, pz + h);
-            const float v2 = leaf_value<true>(T, sid, no_rec, px - h, py + h, pz - h);
-            const float v3 = leaf_value<true>(T, sid, no_rec, px + h, py + h, pz + h);
-            const bool same = hw == sid;
-            f0 = same ? v0 : f0; f1 = same ? v1 : f1; f2 = same ? v2 : f2; f3 = same ? v3 : f3;
-            hw = same ? SDF_NO_PRIM : hw;
-            todo = __builtin_amdgcn_ballot_w64(hw != SDF_NO_PRIM);
+        uint32_t hf = 0u, hc = 0u;
+        if (hit) {
+            const uint2 fc = reinterpret_cast<const uint2*>(T.chain)[hit_prim];
+            hf = fc.x; hc = fc.y;
         }
+        f0 = leaf_value_lane_chain(T, hit_prim, hf, hc, hit, px + h, py - h, pz - h);
+        f1 = leaf_value_lane_chain(T, hit_prim, hf, hc, hit, px - h, py - h, pz + h);
+        f2 = leaf_value_lane_chain(T, hit_prim, hf, hc, hit, px - h, py + h, pz - h);
+        f3 = leaf_value_lane_chain(T, hit_prim, hf, hc, hit, px + h, py + h, pz + h);
     }
     if (hit) {
         if constexpr (!CHAIN) {
