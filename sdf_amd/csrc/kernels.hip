@@ -1096,6 +1096,9 @@ __device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py,
     // lane k of `done` keeps the k-th primitive this pass has evaluated, and an id found there is not evaluated again
     // (12.3 -> ~6 evaluations per pass on the bench frame).
     uint32_t done = 0xFFFFFFFFu, n_done = 0;
+    uint32_t chain_first = 0xFFFFFFFFu;   // CHAIN: record range whose end point (cx, cy, cz) is at hand (a leaf without a chain: first = 0, count = 0)
+    asm volatile("" : "+v"(chain_first));
+    float cx = px, cy = py, cz = pz;
     do {   // one round per brick the listed lanes stand in (2-3 on the bench frame)
         const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)__builtin_ctzll(pend));
         // the brick's id list: ONE vector load (lane j takes entry j), entries then come by v_readlane -- a scalar
@@ -1112,8 +1115,28 @@ __device__ __forceinline__ bool list_pass(const TreeView& T, float px, float py,
             if (__builtin_amdgcn_ballot_w64(done == id) != 0ull) continue;
             done = (lane == n_done) ? id : done;
             n_done += 1;
+            if constexpr (CHAIN) {
+                // two leaves of one parent share their whole chain (one record range): the second finds the point the
+                // first one left behind
+                uint32_t first, cnt;
+                load_u32x2_scalar(T.chain, id << 3, first, cnt);
+                // (kept in a VGPR between candidates: the march kernel has no SGPR to spare across the rounds)
+                if (first != (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_first)) {
+                    chain_first = first;
+                    asm volatile("" : "+v"(chain_first));
+                    const uint32_t mats = (T.n_leaf * 8u + 63u) & ~63u;
+                    cx = px; cy = py; cz = pz;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const f32x16 M = load_rec64_s48_at(T.chain, mats + ((first + j) << 6));
+                        const float nx = ((M[0] * cx + M[1] * cy) + M[2] * cz) + M[3];
+                        const float ny = ((M[4] * cx + M[5] * cy) + M[6] * cz) + M[7];
+                        const float nz = ((M[8] * cx + M[9] * cy) + M[10] * cz) + M[11];
+                        cx = nx; cy = ny; cz = nz;
+                    }
+                }
+            }
             const f32x16 L = load_rec64_s48(T.leaf, id);
-            acc.offer(leaf_value<CHAIN>(T, id, L, px, py, pz), id);
+            acc.offer(leaf_eval_rec(L, cx, cy, cz), id);   // (not the chain path: cx, cy, cz are the point itself)
             if constexpr (COUNT) {
                 wc.wave_list_evals += 1;
                 const uint32_t want = (has_list && bi == sb && ((gc.mask >> b) & 1u)) ? 1u : 0u;
