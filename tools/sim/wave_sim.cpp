@@ -11,6 +11,7 @@
 #include <queue>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "../../include/sdfgpu.h"
 #include "../../include/sdfhost.h"
@@ -443,7 +444,15 @@ static void wave_step_grid(Lane* L, Stats& st, GridStats& gs, int policy) {
     st.wave_steps++;
     st.by_alive_steps[nalive]++;
     gs.iters++;
-    const bool lists_go = nlist > 0 && !(policy == 1 && ncert > 0);
+    const bool lists_go = nlist > 0 && !((policy == 1 || policy == 2) && ncert > 0);
+    if (lists_go && policy == 2) {   // only the brick most listed lanes stand in takes its step; the others wait
+        std::map<long, int> cnt;
+        auto brick_of = [&](long c) { long x = c % G.n, y = (c / G.n) % G.n, z = c / ((long)G.n * G.n); return ((z / 4) * (G.n / 4) + y / 4) * (G.n / 4) + x / 4; };
+        for (int i = 0; i < 64; ++i) if (cellof[i] >= 0) cnt[brick_of(cellof[i])]++;
+        long bestb = -1; int bestc = 0;
+        for (auto& kv : cnt) if (kv.second > bestc) { bestc = kv.second; bestb = kv.first; }
+        for (int i = 0; i < 64; ++i) if (cellof[i] >= 0 && brick_of(cellof[i]) != bestb) { cellof[i] = -2; }
+    }
     const bool do_walk = nwalk > 0 && ncert == 0 && nlist == 0;
     if (do_walk) {
         st.wave_walks++;
@@ -495,6 +504,7 @@ static void wave_step_grid(Lane* L, Stats& st, GridStats& gs, int policy) {
         bool adv;
         if (l.certified) adv = true;
         else if (cellof[i] >= 0) adv = lists_go;
+        else if (cellof[i] == -2) adv = false;
         else adv = do_walk;
         if (!adv) continue;
         if (l.certified) gs.cert_lanes++;
