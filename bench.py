@@ -287,11 +287,26 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
             kms.append(e0.elapsed_time(e1))
         call_ms = float(np.mean(kms))
         tr, trn = profiled_traffic("knn_kernel<1, 8, false")
+        whole_call = None
+        try:   # FETCH_SIZE + WRITE_SIZE of every kernel of one unsorted k = 8 call (tools/query_traffic.sh, committed under profiles/)
+            import glob
+            qt = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "query_traffic.json")))
+            if qt:
+                with open(qt[-1]) as f:
+                    row = json.load(f)["unsorted_k8"]
+                whole_call = {"fetched_MB": row["fetched_MB"], "written_MB": row["written_MB"], "algorithmic_MB": row["algorithmic_MB"],
+                              "ratio": row["ratio"], "source": os.path.relpath(qt[-1], ROOT),
+                              "note": "all kernels of one call (keys, sort, walk); the excess over 1 is the random permutation of 10 M small "
+                                      "items at the memory system's granularity (64-byte fetches for 16-byte points, 32-byte sectors for "
+                                      "8-byte sort pairs), not re-reads: the caller-sorted call moves 1.1x"}
+        except (OSError, ValueError, KeyError):
+            whole_call = None
         out["roofline"] = roofline_object(st, call_ms, "sdfgpu::knn_kernel<1, 8, false, false>", n * 16 + n * k * 8 + int(info.device_bytes),
                                           note="kernel_ms_avg = the whole sdfgpu_knn_dev call (curve keys + radix sort + walk) under HIP "
                                                "events, so the kernel's own rate is higher (profiles/ has its rocprofv3 duration); fp32 "
                                                "VALU-bound walk, K-slot insertion counted as 2 flops per offered primitive",
                                           traffic=tr, traffic_note=trn)
+        out["roofline"]["whole_call_traffic"] = whole_call
         out["work"] = {"inner_visits_per_query": st["inner_visits"] / max(1, st["queries"]),
                        "inner_needed_per_query": st["inner_needed"] / max(1, st["queries"]),
                        "leaf_evals_per_query": (st["sphere_evals"] + st["box_evals"]) / max(1, st["queries"]),

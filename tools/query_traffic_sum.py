@@ -24,7 +24,8 @@ for case in ("unsorted", "presorted"):
                     if r["Counter_Name"] != ctr:
                         continue
                     kn = r["Kernel_Name"]
-                    kn = "walk" if ("nearest_kernel" in kn or "knn_kernel" in kn) else ("keys" if "morton_kernel" in kn else ("sort" if "rocprim" in kn else None))
+                    # round 3: the library's own two-digit sort (rs_keys_hist computes the keys as well) in place of morton_kernel + rocprim
+                    kn = "walk" if ("nearest_kernel" in kn or "knn_kernel" in kn) else ("keys" if ("morton_kernel" in kn or "rs_keys_hist" in kn) else ("sort" if ("rocprim" in kn or "::rs_" in kn) else None))
                     if kn:
                         per[kn].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
             # the last batch: the last walk launch and the key / sort launches after the walk launch before it
