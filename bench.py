@@ -307,6 +307,7 @@ def knn_leg(a, rank, world, local_rank, dev, dist):
                                                "VALU-bound walk, K-slot insertion counted as 2 flops per offered primitive",
                                           traffic=tr, traffic_note=trn)
         out["roofline"]["whole_call_traffic"] = whole_call
+        out["roofline"]["valu_issue"] = issue_utilisation("knn_kernel<1, 8, false", call_ms)   # of the whole call (sort included)
         out["work"] = {"inner_visits_per_query": st["inner_visits"] / max(1, st["queries"]),
                        "inner_needed_per_query": st["inner_needed"] / max(1, st["queries"]),
                        "leaf_evals_per_query": (st["sphere_evals"] + st["box_evals"]) / max(1, st["queries"]),
@@ -360,6 +361,40 @@ def profiled_traffic(kernel_substr="render_pass_kernel<1, false, true, false"):
     if best is None:
         return None, "no PMC profile committed"
     return best[1], "bytes per launch, FETCH_SIZE + WRITE_SIZE from " + os.path.relpath(best[0], os.path.dirname(os.path.abspath(__file__)))
+
+
+def profiled_counter(kernel_substr, counter):
+    """Mean per launch of one committed PMC counter of exactly this instantiation (latest profile), or None."""
+    import glob
+    import json as _json
+    val = None
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_by_kernel.json"))):
+        try:
+            with open(path) as f:
+                d = _json.load(f)
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if (k.endswith(kernel_substr + ">") or k.endswith(kernel_substr + ", false>")) and counter in v:
+                val = (v[counter]["mean_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))))
+    return val
+
+
+VALU_NS_PER_INST_PER_SIMD = 1.09   # tools/ubench/issue_rates.hip: a SIMD with 8 resident wavefronts retires one plain fp32 VALU instruction per 1.09 ns
+N_SIMDS = 1024
+
+
+def issue_utilisation(kernel_substr, kernel_ms):
+    """How busy the kernel keeps the vector pipes: SQ_INSTS_VALU (committed PMC pass) x the measured issue time of one
+    instruction / SIMDs / kernel time.  This -- not flops -- is the wall these walks run into."""
+    c = profiled_counter(kernel_substr, "SQ_INSTS_VALU")
+    if c is None or kernel_ms <= 0:
+        return None
+    busy_ms = c[0] * VALU_NS_PER_INST_PER_SIMD * 1e-6 / N_SIMDS
+    return {"valu_instructions_per_launch": c[0], "ns_per_instruction_per_simd": VALU_NS_PER_INST_PER_SIMD, "simds": N_SIMDS,
+            "issue_bound_ms": busy_ms, "frac_of_kernel_time": busy_ms / kernel_ms, "source": c[1],
+            "note": "wave-level vector instructions x measured issue time (tools/ubench/issue_rates.hip) / 1024 SIMDs: the time the "
+                    "kernel would take if every SIMD issued back to back"}
 
 
 def roofline_object(st, kernel_ms, kernel_name, bytes_alg, note, traffic=None, traffic_note=None):
@@ -872,6 +907,7 @@ def main():
                 note="fp32 VALU-bound tree walk, no dense contraction (no MFMA); kernel_ms_avg = isolated launches under "
                      "HIP events on the launch stream, outside the timed region",
                 traffic=traffic, traffic_note=traffic_note)
+            line["roofline"]["valu_issue"] = issue_utilisation("render_pass_kernel<1, false, true, false", k_avg)
             line["roofline"]["frac_at_throughput"] = W.algorithmic_flops_needed(st) / (ms * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS
             if int(info.grid_cells) > 0:
                 # The candidate grid (round 3) removed most of the algorithm's own work, so `frac` fell while the frame
