@@ -1738,7 +1738,8 @@ __device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict
     const int lead = (int)__builtin_ctzll(lm);
     uint32_t i = 0;
     for (;;) {
-        const GpuGenNode* __restrict__ N = nodes + i;
+        const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
+        const GpuGenNode* const N = &Nv;
         const uint32_t lv = N->level;
         const float4 q4 = stk[(lv - 1u) * 64u + lane];
         bool want;
@@ -1798,7 +1799,8 @@ __device__ __forceinline__ float gen_seed_value(const GpuGenNode* __restrict__ n
     const int lead = (int)__builtin_ctzll(lm);
     uint32_t i = 0;
     for (;;) {
-        const GpuGenNode* __restrict__ N = nodes + i;
+        const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
+        const GpuGenNode* const N = &Nv;
         const uint32_t lv = N->level;
         const float4 q4 = pt[(lv - 1u) * 64u + lane];
         const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
@@ -1846,7 +1848,8 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
     uint32_t i = 0;
     bool second_visit = false;   // node i is the child that waited: its sibling's result is in the frame
     for (;;) {
-        const GpuGenNode* __restrict__ N = nodes + i;
+        const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
+        const GpuGenNode* const N = &Nv;
         const uint32_t lv = N->level;
         const float4 q4 = S.pt[(lv - 1u) * 64u + lane];
         const float base = S.cut[lv * 64u + lane];
