@@ -641,6 +641,7 @@ int sdfgpu_upload_tree_ext(sdfgpu_ctx* c, const SdfOperationBlock* dt, const Sdf
     c->tree.n_gen = (uint32_t)t.gen.size();
     c->tree.gen_eval = t.gen_eval;
     c->tree.gen_prune = t.gen_prune;
+    c->tree.gen_pt_levels = t.gen_pt_levels;
     c->tree.root_ref = t.root_ref;
     c->tree.n_leaf = (uint32_t)t.leaves.size();
     c->tree.stack_depth = t.stack_depth;

@@ -465,17 +465,25 @@ void gen_prune_data(const Ctx& c, const SdfOperationBlock* dt, size_t n, const s
             G[g].skip_to = next_live[i + dt[i].len + 1u];
         }
     }
-    // up_skip, parent_k, first primitive / primitive count of internal nodes
+    // parent_k, point-stack slots (parents come first), first primitive / primitive count of internal nodes
+    uint32_t pt_levels = 1;
+    bool pt_ok = true;
     for (uint32_t g = 0; g < ng; ++g) {
         GpuGenNode& N = G[g];
         const uint32_t pg = N.parent;
-        N.up_skip = 0;
         N.parent_k = 0.f;
+        uint32_t in = 0;
         if (pg != REF_NONE) {
             N.parent_k = G[pg].smooth_k;
-            if (N.skip_to == G[pg].skip_to) N.up_skip = 1u + G[pg].up_skip;   // the parent's subtree ends here too (parents come first)
+            in = (G[pg].pt_slots >> 8) & 0xFFu;
         }
+        const bool pass = !N.is_leaf && N.op == GEN_OP_UNION && is_identity(N.m);
+        const uint32_t out_slot = (N.is_leaf || pass) ? in : in + 1u;
+        if (out_slot > 250u) pt_ok = false;
+        N.pt_slots = in | ((out_slot & 0xFFu) << 8) | (pass ? 1u << 16 : 0u);
+        pt_levels = std::max(pt_levels, out_slot + 1u);
     }
+    out->gen_pt_levels = pt_levels;
     for (uint32_t g = ng; g-- > 0;) {
         GpuGenNode& N = G[g];
         if (N.is_leaf) continue;
@@ -493,7 +501,7 @@ void gen_prune_data(const Ctx& c, const SdfOperationBlock* dt, size_t n, const s
     out->gen_prune = false;
     // (small trees: the exhaustive walk of a few hundred nodes is cheaper than bounds and cuts -- 79 nodes: 3.7 vs 6.0 ms
     // for the test frame)
-    if (!maps_ok || !env_on || ng < 256) return;
+    if (!maps_ok || !env_on || ng < 256 || !pt_ok) return;
     std::vector<Box3> box(ng);
     std::vector<double> slack(ng, 0.0);
     std::vector<uint8_t> has(ng, 0);

@@ -81,7 +81,11 @@ struct alignas(64) GpuGenNode {
     // least the distance to it minus `slack` (what the smooth unions inside can take off a minimum: k/4 per level)
     float bc[3], bh[3];
     float slack;
-    uint32_t up_skip;  // proper ancestors whose subtree ends where this node's does: combined right after it when it is skipped
+    // pruned walks: where the point handed to this node lives in the per-lane point stack (bits 0-7), where the point it
+    // hands down goes (bits 8-15), and bit 16: a plain union with an identity trans_inverse hands its own point on
+    // unchanged (no product, no new slot) -- which is nearly every internal node, so the stack is a few slots deep
+    // instead of one per level
+    uint32_t pt_slots;
     float parent_k;    // smooth radius in effect at the parent (0: plain minimum, clone, or no parent)
 };
 static_assert(sizeof(GpuGenNode) == 192, "GpuGenNode is three 64-byte lines");
@@ -106,6 +110,7 @@ struct CompactTree {
     std::vector<GpuGenNode> gen;        // general path (empty otherwise)
     bool gen_eval = false;              // general path must run the post-order combine (a smooth union is in effect)
     bool gen_prune = false;             // general path: every node carries a valid box (rigid affine maps throughout): the walks prune
+    uint32_t gen_pt_levels = 0;         // pruned walks: slots of the per-lane point stack (GpuGenNode::pt_slots)
     std::vector<GpuLeaf> leaves;
     std::vector<GpuInner> inner;        // AABB mode
     std::vector<GpuInnerObb> inner_obb; // OBB mode

@@ -1690,10 +1690,10 @@ __device__ __forceinline__ void walk_eval(const GpuGenNode* __restrict__ nodes, 
     out_id = S.id[64u + lane].x;
 }
 
-__device__ __forceinline__ EvalStacks eval_stacks(float4* base, uint32_t levels) {
+__device__ __forceinline__ EvalStacks eval_stacks(float4* base, uint32_t pt_slots, uint32_t levels) {
     EvalStacks S;
     S.pt = base;
-    S.d = reinterpret_cast<float2*>(base + (size_t)(levels + 1u) * 64u);
+    S.d = reinterpret_cast<float2*>(base + (size_t)pt_slots * 64u);
     S.id = reinterpret_cast<uint2*>(S.d + (size_t)(levels + 2u) * 64u);
     S.cut = reinterpret_cast<float*>(S.id + (size_t)(levels + 2u) * 64u);
     S.ctl = nullptr;   // set by the kernel (the control stack sits at the end of the block's LDS)
@@ -1741,7 +1741,8 @@ __device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict
         const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
         const GpuGenNode* const N = &Nv;
         const uint32_t lv = N->level;
-        const float4 q4 = stk[(lv - 1u) * 64u + lane];
+        const uint32_t ps = N->pt_slots;
+        const float4 q4 = stk[(ps & 0xFFu) * 64u + lane];
         bool want;
         if (any_only) {
             const uint32_t first = N->prim, cnt = N->is_leaf ? 1u : N->kind;
@@ -1751,14 +1752,14 @@ __device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict
         }
         bool descended = false;
         if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-            const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+            const P4 r = (ps >> 16) ? P4{q4.x, q4.y, q4.z, q4.w} : mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});   // (bit 16: identity map, plain union)
             if (N->is_leaf) {
                 const float d = prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
                 if (only == SDF_NO_PRIM || only == N->prim) acc.offer(d, N->prim);
             } else {
                 const P4 c = down_point(N, r);
                 const float4 c4 = make_float4(c.x, c.y, c.z, c.w);
-                stk[lv * 64u + lane] = c4;
+                if (!(ps >> 16)) stk[((ps >> 8) & 0xFFu) * 64u + lane] = c4;
                 const uint32_t k0 = i + 1u;
                 if (k0 < N->skip_to) {
                     const uint32_t k1 = nodes[k0].skip_to;
@@ -1801,13 +1802,13 @@ __device__ __forceinline__ float gen_seed_value(const GpuGenNode* __restrict__ n
     for (;;) {
         const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
         const GpuGenNode* const N = &Nv;
-        const uint32_t lv = N->level;
-        const float4 q4 = pt[(lv - 1u) * 64u + lane];
-        const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+        const uint32_t ps = N->pt_slots;
+        const float4 q4 = pt[(ps & 0xFFu) * 64u + lane];
+        const P4 r = (ps >> 16) ? P4{q4.x, q4.y, q4.z, q4.w} : mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});   // (bit 16: identity map, plain union)
         if (N->is_leaf) return prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
         const P4 c = down_point(N, r);
         const float4 c4 = make_float4(c.x, c.y, c.z, c.w);
-        pt[lv * 64u + lane] = c4;
+        if (!(ps >> 16)) pt[((ps >> 8) & 0xFFu) * 64u + lane] = c4;
         const uint32_t k0 = i + 1u;
         if (k0 >= N->skip_to) return __builtin_inff();   // nothing live below
         const uint32_t k1 = nodes[k0].skip_to;
@@ -1851,7 +1852,8 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
         const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
         const GpuGenNode* const N = &Nv;
         const uint32_t lv = N->level;
-        const float4 q4 = S.pt[(lv - 1u) * 64u + lane];
+        const uint32_t ps = N->pt_slots;
+        const float4 q4 = S.pt[(ps & 0xFFu) * 64u + lane];
         const float base = S.cut[lv * 64u + lane];
         float cut = base;
         if (second_visit) {
@@ -1864,7 +1866,7 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
         const bool want = live && !(gen_lower_bound(N, q4, scene_T) >= cut);
         bool descended = false;
         if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-            const P4 r = mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});
+            const P4 r = (ps >> 16) ? P4{q4.x, q4.y, q4.z, q4.w} : mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});   // (bit 16: identity map, plain union)
             if (N->is_leaf) {
                 const float v = prim_value_gen(N->kind, N->param, r.x, r.y, r.z);
                 float2 dd = S.d[lv * 64u + lane];
@@ -1875,7 +1877,7 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
             } else {
                 const P4 c = down_point(N, r);
                 const float4 c4 = make_float4(c.x, c.y, c.z, c.w);
-                S.pt[lv * 64u + lane] = c4;
+                if (!(ps >> 16)) S.pt[((ps >> 8) & 0xFFu) * 64u + lane] = c4;
                 S.d[(lv + 1u) * 64u + lane] = make_float2(__builtin_inff(), __builtin_inff());   // faux_shader.rs:177
                 S.id[(lv + 1u) * 64u + lane] = make_uint2(SDF_NO_PRIM, SDF_NO_PRIM);
                 const float k = N->smooth_k;
@@ -1966,7 +1968,7 @@ __global__ __launch_bounds__(64) void query_general_kernel(const GpuGenNode* __r
         if (eval_levels) {   // a combine that is not a plain minimum is in effect: the real post-order evaluation
             float d;
             uint32_t id;
-            EvalStacks S = eval_stacks(gstk, eval_levels);
+            EvalStacks S = eval_stacks(gstk, prune ? prune : eval_levels + 1u, eval_levels);
             S.ctl = ctl;
             if (prune) {
                 const bool live = alive && in_dom;
@@ -2047,7 +2049,7 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
         if (prune) {
             const float U = gen_seed_value(nodes, n_nodes, P4{px, py, pz, 1.0f}, alive, scene_T, gstk, lane);
             if (eval_levels) {
-                EvalStacks S = eval_stacks(gstk, eval_levels);
+                EvalStacks S = eval_stacks(gstk, prune ? prune : eval_levels + 1u, eval_levels);
                 S.ctl = ctl;
                 walk_eval_pruned(nodes, n_nodes, P4{px, py, pz, 1.0f}, S, alive, scene_T, U + 1.0e-5f * __builtin_fabsf(U) + 1.0e-30f, lane,
                                  acc.best, acc.bid);
@@ -2055,7 +2057,7 @@ __global__ __launch_bounds__(64) void render_general_kernel(const GpuGenNode* __
                 acc.best = U;
                 walk_general_pruned(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, false, alive, scene_T, acc, gstk, ctl, lane);
             }
-        } else if (eval_levels) walk_eval(nodes, n_nodes, P4{px, py, pz, 1.0f}, eval_stacks(gstk, eval_levels), lane, acc.best, acc.bid);
+        } else if (eval_levels) walk_eval(nodes, n_nodes, P4{px, py, pz, 1.0f}, eval_stacks(gstk, eval_levels + 1u, eval_levels), lane, acc.best, acc.bid);
         else walk_general(nodes, n_nodes, P4{px, py, pz, 1.0f}, SDF_NO_PRIM, acc, gstk, lane);
         if (alive) {
             if (acc.best < mp.eps_hit) { hit = true; hit_prim = acc.bid; alive = false; }
@@ -2207,7 +2209,7 @@ static hipError_t launch_nearest_t(const DeviceTree& d, const float* pts, const 
 // results (distance, index) of every level.
 static uint32_t general_eval_levels(const DeviceTree& d) { return d.gen_eval ? d.stack_depth : 0u; }
 static size_t general_ctl_off(const DeviceTree& d) {   // where the pruned walks' control stack starts: behind everything else
-    size_t b = (size_t)(d.stack_depth + 1u) * 64u * sizeof(float4);
+    size_t b = (size_t)(d.gen_prune ? d.gen_pt_levels : d.stack_depth + 1u) * 64u * sizeof(float4);
     if (d.gen_eval) b += (size_t)(d.stack_depth + 2u) * 64u * (sizeof(float2) + sizeof(uint2) + sizeof(float));
     return b;
 }
@@ -2224,7 +2226,7 @@ hipError_t launch_nearest(const DeviceTree& d, const float* pts, const uint32_t*
                           uint32_t* out_prim, sdfgpu_stats* st, hipStream_t s, bool stats_asm_walk) {
     if (d.gen) {   // general path: exhaustive literal chain (no counters, no reordering needed)
         if (n == 0) return hipSuccess;
-        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), d.gen_prune ? 1u : 0u,
+        query_general_kernel<1><<<dim3((n + 63u) / 64u), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), d.gen_prune ? d.gen_pt_levels : 0u,
                                                                                        d.margin_T, (uint32_t)general_ctl_off(d), (const float4*)pts, order, n, 1, out_dist, out_prim);
         return hipGetLastError();
     }
@@ -2256,10 +2258,10 @@ hipError_t launch_knn(const DeviceTree& d, const float* pts, const uint32_t* ord
         dim3 grid((n + 63u) / 64u), block(64);
         const size_t lds = general_lds(d);
         const float4* p4 = (const float4*)pts;
-        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
-        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
-        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
-        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        if (k <= 2) query_general_kernel<2><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? d.gen_pt_levels : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        else if (k <= 4) query_general_kernel<4><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? d.gen_pt_levels : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        else if (k <= 8) query_general_kernel<8><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? d.gen_pt_levels : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
+        else query_general_kernel<16><<<grid, block, lds, s>>>(d.gen, d.n_gen, 0u, d.gen_prune ? d.gen_pt_levels : 0u, d.margin_T, (uint32_t)general_ctl_off(d), p4, order, n, k, out_dist, out_prim);
         return hipGetLastError();
     }
     if (d.chain) {
@@ -2340,7 +2342,7 @@ hipError_t launch_render(const DeviceTree& d, const sdfgpu_camera& cam, uint32_t
                          uint8_t* hit, float* depth, float* normal, uint32_t* prim, sdfgpu_stats* st, hipStream_t s) {
     if (tile_count == 0) return hipSuccess;
     if (d.gen) {
-        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), d.gen_prune ? 1u : 0u, d.margin_T, (uint32_t)general_ctl_off(d), cam, w, h, mp, tile_first,
+        render_general_kernel<<<dim3(tile_count), dim3(64), general_lds(d), s>>>(d.gen, d.n_gen, general_eval_levels(d), d.gen_prune ? d.gen_pt_levels : 0u, d.margin_T, (uint32_t)general_ctl_off(d), cam, w, h, mp, tile_first,
                                                                                 tile_stride, tile_count, row_major ? 1u : 0u,
                                                                                 hit, depth, normal, prim);
         return hipGetLastError();

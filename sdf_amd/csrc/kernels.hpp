@@ -66,6 +66,7 @@ struct DeviceTree {
     uint32_t n_gen = 0;
     bool gen_eval = false;              // general path runs the post-order combine (smooth union in effect)
     bool gen_prune = false;             // general path: nodes carry boxes, the walks skip subtrees (gpu_tree.hpp GpuGenNode)
+    uint32_t gen_pt_levels = 0;         // ... and their per-lane point stack has this many slots
     uint32_t root_ref = REF_NONE;
     uint32_t n_leaf = 0;
     uint32_t stack_depth = 1;
