@@ -88,6 +88,11 @@ pub const OPT_CANDIDATE_GRID: i32 = 6;
 pub const EXT_SMOOTH_UNION: u32 = 1;
 pub const EXT_BOX_FRAME: u32 = 2;
 pub const EXT_CLONE_REPAIR: u32 = 4;
+/// sdfgpu_walk (SdfGpuTreeInfo::walk): which resident form serves the tree; results never depend on it
+pub const WALK_HIERARCHY: u32 = 0;
+pub const WALK_CHAIN: u32 = 1;
+pub const WALK_GENERAL_PRUNED: u32 = 2;
+pub const WALK_GENERAL_EXHAUSTIVE: u32 = 3;
 /// `sdfgpu_nearest_dev_static` takes at most this many points per call.
 pub const STATIC_MAX_POINTS: usize = 262_144;
 pub const COMM_ID_BYTES: usize = 128;
