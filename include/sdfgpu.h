@@ -79,7 +79,8 @@ typedef struct sdfgpu_tree_info {
     float scene_lo[3];       /* root AABB (AABB mode) */
     float scene_hi[3];
     uint32_t extensions;     /* sdfgpu_extension bits that are in effect in this tree (0 = evaluated as the crate is written) */
-    uint32_t grid_cells;     /* cells of the nearest-candidate grid built for the march (0 = none); its bytes are part of device_bytes */
+    uint32_t grid_cells;     /* cells of the nearest-candidate grid (0 = none): march steps and k = 1 queries inside it are decided on
+                                a cell's list, k-nearest queries start from its radius cap; its bytes are part of device_bytes */
     uint32_t walk;           /* sdfgpu_walk: which resident form serves this tree's queries */
     uint32_t reserved;
 } sdfgpu_tree_info;
@@ -268,12 +269,13 @@ typedef enum sdfgpu_option {
      * asynchronous.  Off by default: on MI355X every extra chunk cost ~0.3 ms on the 10 M point batch
      * (2.15 ms in one piece, 2.46 / 3.02 / 4.22 ms in 2 / 4 / 8 chunks). */
     SDFGPU_OPT_QUERY_PIPELINE = 5,
-    /* render: 1 (default): sdfgpu_upload_tree also builds the nearest-candidate grid (a uniform grid over the
-     * padded scene box whose cells list every primitive that can be nearest anywhere in the cell; about 10 bytes
-     * per cell, ~400 cells per primitive, at most 32 M cells), and march steps inside it are decided on a cell's
-     * list instead of a tree walk.  0: no grid (set BEFORE the upload; a tree already resident keeps what it
-     * has).  Built for pruned trees (AABB / BVH bounds) of at least 64 primitives.  Results are identical
-     * either way. */
+    /* 1 (default): sdfgpu_upload_tree also builds the nearest-candidate grid (a uniform grid over the padded
+     * scene box whose cells list every primitive that can be nearest anywhere in the cell, and bound the
+     * distance of the 8th / 16th nearest; about 18 bytes per cell, ~400 cells per primitive, at most 32 M
+     * cells): march steps and k = 1 queries inside it are decided on a cell's list instead of a tree walk,
+     * k-nearest queries start with their prune radius capped.  0: no grid (set BEFORE the upload; a tree
+     * already resident keeps what it has).  Built for pruned trees (AABB / BVH / OBB bounds, chain path
+     * included) of at least 64 primitives.  Results are identical either way. */
     SDFGPU_OPT_CANDIDATE_GRID = 6
 } sdfgpu_option;
 int sdfgpu_set_option(sdfgpu_ctx* ctx, int option, double value);
