@@ -1737,6 +1737,9 @@ __device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict
     if (lm == 0ull || n == 0u) return;
     const int lead = (int)__builtin_ctzll(lm);
     uint32_t i = 0;
+    // the bound of the child descended into was formed when its parent ordered its children: not formed again
+    float carried_lb = 0.f;
+    bool have_lb = false;
     for (;;) {
         const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
         const GpuGenNode* const N = &Nv;
@@ -1748,8 +1751,9 @@ __device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict
             const uint32_t first = N->prim, cnt = N->is_leaf ? 1u : N->kind;
             want = live && only != SDF_NO_PRIM && (only - first) < cnt;
         } else {
-            want = live && !(gen_lower_bound(N, q4, scene_T) > acc.radius());
+            want = live && !((have_lb ? carried_lb : gen_lower_bound(N, q4, scene_T)) > acc.radius());
         }
+        have_lb = false;
         bool descended = false;
         if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
             const P4 r = (ps >> 16) ? P4{q4.x, q4.y, q4.z, q4.w} : mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});   // (bit 16: identity map, plain union)
@@ -1769,6 +1773,8 @@ __device__ __forceinline__ void walk_general_pruned(const GpuGenNode* __restrict
                         const uint32_t pick1 = (uint32_t)__builtin_amdgcn_readlane((int)((b1 < b0) ? 1u : 0u), lead);
                         first = pick1 ? k1 : k0;
                         second = pick1 ? k0 : k1;
+                        carried_lb = pick1 ? b1 : b0;
+                        have_lb = true;
                     }
                     ctl[lv] = second;
                     i = first;
@@ -1847,6 +1853,8 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
     if (lm == 0ull || n == 0u) return;
     const int lead = (int)__builtin_ctzll(lm);
     uint32_t i = 0;
+    float carried_lb = 0.f;      // the bound of the child descended into, formed when its parent ordered its children
+    bool have_lb = false;
     bool second_visit = false;   // node i is the child that waited: its sibling's result is in the frame
     for (;;) {
         const GpuGenNode Nv = nodes[i];   // the whole record at once: one memory round trip per visit, not one per field
@@ -1863,7 +1871,8 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
             cut = cut + 1.0e-5f * (__builtin_fabsf(cut) + pk) + 1.0e-30f;
         }
         second_visit = false;
-        const bool want = live && !(gen_lower_bound(N, q4, scene_T) >= cut);
+        const bool want = live && !((have_lb ? carried_lb : gen_lower_bound(N, q4, scene_T)) >= cut);
+        have_lb = false;
         bool descended = false;
         if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
             const P4 r = (ps >> 16) ? P4{q4.x, q4.y, q4.z, q4.w} : mat4_mul(N->m, P4{q4.x, q4.y, q4.z, q4.w});   // (bit 16: identity map, plain union)
@@ -1892,6 +1901,8 @@ __device__ __forceinline__ void walk_eval_pruned(const GpuGenNode* __restrict__ 
                         const uint32_t pick1 = (uint32_t)__builtin_amdgcn_readlane((int)((b1 < b0) ? 1u : 0u), lead);
                         first = pick1 ? k1 : k0;
                         second = pick1 ? k0 : k1;
+                        carried_lb = pick1 ? b1 : b0;
+                        have_lb = true;
                     }
                     S.ctl[lv] = second;
                     i = first;
